@@ -1,0 +1,366 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the *reference* solver.
+
+Runs ONLY in the build container (needs /root/reference; the reference never
+travels to the GPU box).  Output: ``tests/golden/cases.json`` (small cases with
+the instance inline) and ``tests/golden/<name>.npz`` + entries in
+``tests/golden/synthetic.json`` (seeded generator instances, arrays stored so
+the tests never depend on numpy's RNG stream staying stable).
+
+Reference call convention:
+    SolverOptions(auto_scale=False, pricing_strategy=<rule>, explicit_pricing_strategy=True)
+``auto_scale=False`` because the reference's float rescaling destroys
+integrality (/root/reference/src/network_solver/scaling.py:37-95).
+
+Each expected record is cross-checked against ``networkx.network_simplex``
+(integer-exact) before it is written.
+
+    python3 tests/golden/make_golden.py
+"""
+
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import random
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parents[1]
+REF = Path("/root/reference")
+sys.path.insert(0, str(REF / "src"))
+sys.path.insert(0, str(REPO))
+
+import networkx as nx  # noqa: E402
+from network_solver import (  # type: ignore  # noqa: E402
+    SolverOptions,
+    build_problem,
+    load_problem,
+    solve_min_cost_flow,
+)
+from network_solver.exceptions import UnboundedProblemError  # type: ignore  # noqa: E402
+
+from network_flow_solver_amd import generators  # noqa: E402
+
+STRATEGIES = ("dantzig", "devex")
+
+
+def run_reference(problem, strategy: str, max_iterations=None) -> dict:
+    opts = SolverOptions(
+        auto_scale=False, pricing_strategy=strategy, explicit_pricing_strategy=True
+    )
+    buf = io.StringIO()
+    t0 = time.time()
+    try:
+        with contextlib.redirect_stdout(buf):
+            res = solve_min_cost_flow(problem, options=opts, max_iterations=max_iterations)
+    except UnboundedProblemError as exc:
+        return {"status": "unbounded", "entering_arc": list(exc.entering_arc or ())}
+    dt = time.time() - t0
+    return {
+        "status": res.status,
+        "objective": res.objective,
+        "iterations": res.iterations,
+        "flows": sorted([[t, h, f] for (t, h), f in res.flows.items()]),
+        "ref_solve_seconds": round(dt, 4),
+    }
+
+
+def networkx_objective(nodes, arcs, directed=True):
+    """Integer-exact second opinion (only for directed, lower=0, finite integer data)."""
+    if not directed:
+        return None
+    g = nx.DiGraph()
+    for nd in nodes:
+        g.add_node(nd["id"], demand=-int(round(nd.get("supply", 0.0))))
+    for a in arcs:
+        if a.get("lower", 0.0):
+            return None
+        if g.has_edge(a["tail"], a["head"]):
+            return None  # parallel arcs: DiGraph cannot hold them
+        kw = {"weight": int(round(a.get("cost", 0.0)))}
+        if abs(a.get("cost", 0.0) - kw["weight"]) > 1e-12:
+            return None
+        if a.get("capacity") is not None:
+            kw["capacity"] = int(round(a["capacity"]))
+            if abs(a["capacity"] - kw["capacity"]) > 1e-12:
+                return None
+        g.add_edge(a["tail"], a["head"], **kw)
+    try:
+        cost, _ = nx.network_simplex(g)
+    except nx.NetworkXUnfeasible:
+        return "infeasible"
+    except nx.NetworkXUnbounded:
+        return "unbounded"
+    return cost
+
+
+def make_case(name, nodes, arcs, directed=True, tolerance=1e-6, source="", max_iterations=None):
+    problem = build_problem(nodes=nodes, arcs=arcs, directed=directed, tolerance=tolerance)
+    expected = {s: run_reference(problem, s, max_iterations) for s in STRATEGIES}
+    nxo = networkx_objective(nodes, arcs, directed)
+    for s, e in expected.items():
+        if e["status"] == "optimal" and isinstance(nxo, (int, float)):
+            assert abs(e["objective"] - nxo) < 1e-6, (name, s, e["objective"], nxo)
+        if e["status"] == "infeasible":
+            assert nxo in ("infeasible", None), (name, nxo)
+    print(f"  {name}: " + ", ".join(f"{s}={e['status']}/{e.get('objective')}/{e.get('iterations')}" for s, e in expected.items()))
+    return {
+        "name": name,
+        "source": source,
+        "directed": directed,
+        "tolerance": tolerance,
+        "max_iterations": max_iterations,
+        "nodes": nodes,
+        "arcs": arcs,
+        "expected": expected,
+        "networkx_objective": nxo,
+    }
+
+
+def json_fixture_case(name, path, source):
+    payload = json.loads(Path(path).read_text())
+    nodes = payload["nodes"]
+    arcs = payload.get("edges") or payload.get("arcs")
+    arcs = [
+        {
+            "tail": a["tail"],
+            "head": a["head"],
+            "capacity": a.get("capacity"),
+            "cost": a.get("cost", 0.0),
+            "lower": a.get("lower", 0.0),
+        }
+        for a in arcs
+    ]
+    # sanity: the reference's own loader must agree with our reading of the file
+    p = load_problem(path)
+    assert len(p.nodes) == len(nodes) and len(p.arcs) == len(arcs)
+    return make_case(
+        name,
+        nodes,
+        arcs,
+        directed=bool(payload.get("directed", True)),
+        tolerance=float(payload.get("tolerance", 1e-3)),
+        source=source,
+    )
+
+
+def dimacs_case(name, path, source):
+    sys.path.insert(0, str(REF))
+    from benchmarks.parsers.dimacs import parse_dimacs_file  # type: ignore
+
+    p = parse_dimacs_file(path)
+    nodes = [{"id": nid, "supply": nd.supply} for nid, nd in p.nodes.items()]
+    arcs = [
+        {"tail": a.tail, "head": a.head, "capacity": a.capacity, "cost": a.cost, "lower": a.lower}
+        for a in p.arcs
+    ]
+    case = make_case(name, nodes, arcs, directed=True, tolerance=p.tolerance, source=source)
+    case["dimacs_text"] = Path(path).read_text()
+    return case
+
+
+def chain_case(name, count, total, prefix, cost_fn, directed, tol, source):
+    nodes = [{"id": f"{prefix}{i}", "supply": 0.0} for i in range(count)]
+    nodes[0]["supply"] = total
+    nodes[-1]["supply"] = -total
+    arcs = [
+        {"tail": f"{prefix}{i}", "head": f"{prefix}{i + 1}", "capacity": total, "cost": float(cost_fn(i)), "lower": 0.0}
+        for i in range(count - 1)
+    ]
+    return make_case(name, nodes, arcs, directed=directed, tolerance=tol, source=source)
+
+
+def perf_chain_case():
+    # tests/integration/test_solver_performance.py:15-56 (seed 24, fractional costs k/5 and k/4)
+    rng = random.Random(24)
+    node_count, total = 160, 1200.0
+    nodes = [{"id": f"n{i}", "supply": 0.0} for i in range(node_count)]
+    nodes[0]["supply"] = total
+    nodes[-1]["supply"] = -total
+    arcs = []
+    for idx in range(node_count - 1):
+        capacity = total + rng.randint(0, 120)
+        cost = 1.0 + (rng.randint(0, 9) / 5.0)
+        arcs.append({"tail": f"n{idx}", "head": f"n{idx + 1}", "capacity": float(capacity), "cost": cost, "lower": 0.0})
+        if idx + 2 < node_count and rng.random() < 0.35:
+            capacity_skip = total + rng.randint(0, 120)
+            cost_skip = 1.5 + (rng.randint(0, 9) / 4.0)
+            arcs.append({"tail": f"n{idx}", "head": f"n{idx + 2}", "capacity": float(capacity_skip), "cost": cost_skip, "lower": 0.0})
+    return make_case("perf_chain_seed24", nodes, arcs, tolerance=1e-6,
+                     source="tests/integration/test_solver_performance.py:15-56")
+
+
+def property_cases(count=24):
+    """Replay of the hypothesis generator's shape with fixed seeds
+    (tests/test_property_min_cost_flow.py:18-107)."""
+    out = []
+    for seed in range(count):
+        rng = random.Random(1000 + seed)
+        sc, dc, rc = rng.randint(1, 4), rng.randint(1, 4), rng.randint(0, 2)
+        sn = [f"s{i}" for i in range(sc)]
+        dn = [f"t{i}" for i in range(dc)]
+        rn = [f"m{i}" for i in range(rc)]
+        supplies = [rng.randint(1, 18) for _ in range(sc)]
+        total = sum(supplies)
+        nodes = [{"id": n, "supply": float(a)} for n, a in zip(sn, supplies)]
+        remaining = total
+        for i, n in enumerate(dn):
+            amt = remaining if i == dc - 1 else rng.randint(0, remaining)
+            remaining -= amt
+            nodes.append({"id": n, "supply": -float(amt)})
+        for n in rn:
+            nodes.append({"id": n, "supply": 0.0})
+        base = max(total, 1)
+        arcs = []
+
+        def add(t, h):
+            arcs.append({"tail": t, "head": h, "capacity": float(rng.randint(base, base + 20)),
+                         "cost": float(rng.randint(1, 12)), "lower": 0.0})
+
+        for t in sn:
+            for h in dn:
+                add(t, h)
+        for r in rn:
+            for s in sn:
+                add(s, r)
+            for d in dn:
+                add(r, d)
+        out.append(make_case(f"property_seed{seed}", nodes, arcs, tolerance=1e-6,
+                             source="tests/test_property_min_cost_flow.py:18-107 (shape replayed, fixed seed)"))
+    return out
+
+
+def misc_cases():
+    out = []
+    # tests/integration/test_solver_end_to_end.py:14-56
+    out.append(make_case("e2e_three_node", [
+        {"id": "s", "supply": 4.0}, {"id": "m", "supply": 0.0}, {"id": "t", "supply": -4.0}], [
+        {"tail": "s", "head": "m", "capacity": 4.0, "cost": 1.0, "lower": 0.0},
+        {"tail": "m", "head": "t", "capacity": 4.0, "cost": 1.0, "lower": 0.0},
+        {"tail": "s", "head": "t", "capacity": 4.0, "cost": 3.0, "lower": 0.0}],
+        source="tests/integration/test_solver_end_to_end.py:14-56"))
+    # tests/unit/test_simplex.py:57-102
+    out.append(make_case("simplex_five_node_70", [
+        {"id": "s", "supply": 10.0}, {"id": "a", "supply": 0.0}, {"id": "b", "supply": 0.0},
+        {"id": "c", "supply": 0.0}, {"id": "t", "supply": -10.0}], [
+        {"tail": "s", "head": "a", "capacity": 10.0, "cost": 5.0, "lower": 0.0},
+        {"tail": "s", "head": "b", "capacity": 10.0, "cost": 4.0, "lower": 0.0},
+        {"tail": "a", "head": "c", "capacity": 10.0, "cost": 1.0, "lower": 0.0},
+        {"tail": "b", "head": "c", "capacity": 10.0, "cost": 2.0, "lower": 0.0},
+        {"tail": "c", "head": "t", "capacity": 10.0, "cost": 1.0, "lower": 0.0}],
+        source="tests/unit/test_simplex.py:57-102"))
+    # tests/unit/test_simplex.py:41-54 (degenerate triangle)
+    out.append(make_case("degenerate_triangle", [
+        {"id": "s", "supply": 1.0}, {"id": "m", "supply": 0.0}, {"id": "t", "supply": -1.0}], [
+        {"tail": "s", "head": "m", "capacity": 5.0, "cost": 200.0, "lower": 0.0},
+        {"tail": "m", "head": "t", "capacity": 5.0, "cost": 1.0, "lower": 0.0},
+        {"tail": "s", "head": "t", "capacity": 5.0, "cost": 2.0, "lower": 0.0}],
+        source="tests/unit/test_simplex.py:41-54"))
+    # tests/test_large_directed.py:73-100
+    out.append(make_case("multi_source_multi_sink_hub", [
+        {"id": "s1", "supply": 10.0}, {"id": "s2", "supply": 5.0}, {"id": "hub", "supply": 0.0},
+        {"id": "t1", "supply": -6.0}, {"id": "t2", "supply": -9.0}], [
+        {"tail": "s1", "head": "hub", "capacity": 10.0, "cost": 1.0, "lower": 0.0},
+        {"tail": "s2", "head": "hub", "capacity": 5.0, "cost": 1.0, "lower": 0.0},
+        {"tail": "hub", "head": "t1", "capacity": 10.0, "cost": 1.0, "lower": 0.0},
+        {"tail": "hub", "head": "t2", "capacity": 10.0, "cost": 1.0, "lower": 0.0}],
+        tolerance=1e-4, source="tests/test_large_directed.py:73-100"))
+    # tests/test_large_directed.py:14-70, 103-128
+    out.append(chain_case("chain120", 120, 750.0, "v", lambda i: 1 + (i % 9), True, 1e-4,
+                          "tests/test_large_directed.py:14-41"))
+    out.append(chain_case("chain80", 80, 500.0, "p", lambda i: 2 + (i % 5), True, 1e-4,
+                          "tests/test_large_directed.py:44-70"))
+    out.append(chain_case("undirected_chain75", 75, 320.0, "u", lambda i: 3 + (i % 4), False, 1e-4,
+                          "tests/test_large_directed.py:103-128"))
+    # tests/integration/test_unbounded_detection.py:15-55
+    out.append(make_case("unbounded_cycle", [
+        {"id": "A", "supply": 0.0}, {"id": "B", "supply": 0.0}], [
+        {"tail": "A", "head": "B", "capacity": None, "cost": -5.0, "lower": 0.0},
+        {"tail": "B", "head": "A", "capacity": None, "cost": 1.0, "lower": 0.0}],
+        tolerance=1e-9, source="tests/integration/test_unbounded_detection.py:15-34"))
+    out.append(make_case("infeasible_capacity_starved", [
+        {"id": "s", "supply": 5.0}, {"id": "m", "supply": 0.0}, {"id": "t", "supply": -5.0}], [
+        {"tail": "s", "head": "m", "capacity": 5.0, "cost": 1.0, "lower": 0.0}],
+        tolerance=1e-9, max_iterations=1000, source="tests/integration/test_unbounded_detection.py:37-55"))
+    # lower bounds + an uncapacitated arc + a parallel pair (simplex.py:403-428, 1703-1721)
+    out.append(make_case("lower_bounds_and_parallel", [
+        {"id": "a", "supply": 12.0}, {"id": "b", "supply": 0.0}, {"id": "c", "supply": -12.0}], [
+        {"tail": "a", "head": "b", "capacity": 10.0, "cost": 2.0, "lower": 3.0},
+        {"tail": "a", "head": "b", "capacity": 4.0, "cost": 1.0, "lower": 0.0},
+        {"tail": "b", "head": "c", "capacity": None, "cost": 1.0, "lower": 2.0},
+        {"tail": "a", "head": "c", "capacity": 6.0, "cost": 7.0, "lower": 1.0}],
+        source="own case: lower-bound shift (simplex.py:413-428), parallel-arc key sum (simplex.py:1703-1721)"))
+    # fractional data (decimal scaling path of the shim)
+    out.append(make_case("fractional_costs", [
+        {"id": "s", "supply": 2.5}, {"id": "m", "supply": 0.0}, {"id": "t", "supply": -2.5}], [
+        {"tail": "s", "head": "m", "capacity": 2.5, "cost": 1.5, "lower": 0.0},
+        {"tail": "m", "head": "t", "capacity": 2.5, "cost": 1.25, "lower": 0.0},
+        {"tail": "s", "head": "t", "capacity": 1.0, "cost": 2.0, "lower": 0.0}],
+        source="own case: non-integer data, cf. tests/unit/test_simplex.py:105-123"))
+    out.append(perf_chain_case())
+    return out
+
+
+def synthetic_entry(inst: generators.ArcSoA, strategies=STRATEGIES):
+    nodes, arcs = generators.to_node_arc_dicts(inst)
+    problem = build_problem(nodes=nodes, arcs=arcs, directed=True, tolerance=1e-6)
+    expected = {s: run_reference(problem, s) for s in strategies}
+    nxo = networkx_objective(nodes, arcs)
+    objs = set()
+    for s, e in expected.items():
+        assert e["status"] == "optimal", (inst.name, s, e["status"])
+        assert isinstance(nxo, (int, float)) and abs(e["objective"] - nxo) < 1e-6, (inst.name, e["objective"], nxo)
+        objs.add(e["objective"])
+    assert len(objs) == 1
+    print(f"  {inst.name}: obj={objs.pop()} " + ", ".join(f"{s}:{e['iterations']}its/{e['ref_solve_seconds']}s" for s, e in expected.items()))
+    fn = inst.name.replace("(synthetic)", "_syn").replace("/", "_")
+    np.savez_compressed(HERE / f"{fn}.npz", n=np.int64(inst.n), tail=inst.tail, head=inst.head,
+                        cost=inst.cost, cap=inst.cap, supply=inst.supply)
+    # flows keyed by 0-based (tail, head) ints for compactness
+    for e in expected.values():
+        e["flows"] = sorted([[int(t) - 1, int(h) - 1, f] for t, h, f in e["flows"]])
+    return {"name": inst.name, "file": f"{fn}.npz", "n": inst.n, "m": inst.m, "sha256": inst.sha256(),
+            "expected": expected, "networkx_objective": nxo}
+
+
+def main():
+    print("small cases")
+    cases = []
+    ex = REF / "examples"
+    cases.append(json_fixture_case("sample_problem", ex / "sample_problem.json",
+                                   "examples/sample_problem.json; tests/integration/test_cli_example.py:69-73 (objective 15.0)"))
+    cases.append(json_fixture_case("dimacs_small_problem", ex / "dimacs_small_problem.json",
+                                   "examples/dimacs_small_problem.json; tests/integration/test_solver_end_to_end.py:57-75 (30.0)"))
+    cases.append(json_fixture_case("textbook_transport", ex / "textbook_transport_problem.json",
+                                   "examples/textbook_transport_problem.json; test_solver_end_to_end.py:78-99 (85.0)"))
+    cases.append(json_fixture_case("large_transport", ex / "large_transport_problem.json",
+                                   "examples/large_transport_problem.json; test_solver_end_to_end.py:102-121 (100.0)"))
+    gen = REF / "benchmarks" / "problems" / "generated"
+    for nm in ("tiny_transportation", "small_transshipment", "simple_assignment"):
+        cases.append(dimacs_case(nm, gen / f"{nm}.min",
+                                 f"benchmarks/problems/generated/{nm}.min; benchmarks/metadata/known_solutions.json:33-57"))
+    cases += misc_cases()
+    cases += property_cases()
+    (HERE / "cases.json").write_text(json.dumps(cases, indent=1))
+
+    print("synthetic generator instances")
+    syn = []
+    syn.append(synthetic_entry(generators.netgen_style(64, 512, seed=1, name="netgen_style_64_512_s1")))
+    syn.append(synthetic_entry(generators.gridgen_style(8, 8, seed=1, name="gridgen_style_8x8_s1")))
+    syn.append(synthetic_entry(generators.goto_style(8, 8, seed=1, name="goto_style_8x8_s1")))
+    for nm in ("netgen_8_08a", "netgen_8_08b", "gridgen_8_08a", "goto_8_08a"):
+        syn.append(synthetic_entry(generators.named_instance(nm)))
+    if "--big" in sys.argv:
+        syn.append(synthetic_entry(generators.named_instance("netgen_8_10a"), strategies=("devex",)))
+    (HERE / "synthetic.json").write_text(json.dumps(syn, indent=1))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
