@@ -1,0 +1,171 @@
+/*
+ * mcf.h -- C ABI of libmcf_hip.so, the MI355X (gfx950) network-simplex pivot engine.
+ *
+ * The reference (jeffreyhorn/network_flow_solver) is pure Python and has no FFI; its
+ * seams are Python-level.  This library is what a ctypes stub
+ * behind those seams binds:
+ *
+ *   reference seam (file:line under /root/reference/src/network_solver/)      entry point here
+ *   -----------------------------------------------------------------------   ----------------
+ *   NetworkSimplex.__init__: arc build, SoA mirror, initial tree
+ *       simplex.py:99-265, 392-456, 619-730 ..................................  mcf_create
+ *   NetworkSimplex.solve / _run_simplex_iterations / _pivot
+ *       simplex.py:1109-1160, 1176-1425, 1446-1701 ...........................  mcf_solve
+ *   result extraction  simplex.py:1703-1765 ..................................  mcf_get_result
+ *   PricingStrategy.select_entering_arc  simplex_pricing.py:57-86, 97-137,
+ *       310-357 and NetworkSimplex._select_entering_arc_vectorized
+ *       simplex.py:528-617 ...................................................  mcf_price_once
+ *   ProgressCallback cadence  simplex.py:1143-1154 ...........................  mcf_progress_cb
+ *   UnboundedProblemError(entering_arc, reduced_cost)  exceptions.py:65-93 ...  MCF_ST_UNBOUNDED + stats.unbounded_arc
+ *
+ * Conventions: plain pointers and sizes only; integer return codes (0 = ok, < 0 =
+ * MCF_E_*), never exceptions; the caller owns every buffer it passes; the library owns
+ * device memory until mcf_destroy; one handle is not thread-safe, distinct handles are
+ * independent.  All problem data are integers: the Python shim scales decimal input
+ * (and applies the reference's lower-bound shift, simplex.py:413-428) before the call.
+ *
+ * There is NO CPU fallback: every compute entry point fails with MCF_E_NO_DEVICE when no
+ * HIP device is usable.
+ */
+#ifndef MCF_H
+#define MCF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCF_ABI_VERSION 1
+
+/* return codes */
+#define MCF_OK 0
+#define MCF_E_BAD_ARG (-1)
+#define MCF_E_NO_DEVICE (-2)
+#define MCF_E_HIP (-3)
+#define MCF_E_ALLOC (-4)
+#define MCF_E_RANGE (-5)     /* value outside what the integer engine represents */
+#define MCF_E_STATE (-6)     /* call not valid in the handle's current state */
+#define MCF_E_INTERNAL (-7)
+
+/* solve status (mcf_get_result) -- mapped by the shim onto the reference's strings
+ * (data.py:269-322): optimal / infeasible / iteration_limit; unbounded becomes
+ * UnboundedProblemError. */
+#define MCF_ST_OPTIMAL 0
+#define MCF_ST_INFEASIBLE 1
+#define MCF_ST_ITERATION_LIMIT 2
+#define MCF_ST_UNBOUNDED 3
+
+/* pricing rules */
+#define MCF_RULE_DANTZIG_FULL 0   /* full-scan most-violating arc (simplex_pricing.py:97-137) */
+#define MCF_RULE_DEVEX_BLOCK 1    /* round-robin block search, merit rc^2/w, deferred weight update
+                                     (simplex_pricing.py:310-357, 271-292) */
+
+/* "uncapacitated" marker accepted in cap[] (besides any value >= 2^60) */
+#define MCF_CAP_INF (-1)
+
+typedef struct mcf_handle mcf_handle;
+
+typedef struct mcf_options {
+    int32_t abi_version;     /* MCF_ABI_VERSION */
+    int32_t device;          /* HIP device ordinal; -1 = current device */
+    int32_t rule;            /* MCF_RULE_* */
+    int32_t batch_pivots;    /* pivots enqueued per host round trip (0 = default 64) */
+    int32_t use_graph;       /* 1 = replay a captured hipGraph of batch_pivots pivots */
+    int32_t profile;         /* 1 = bracket every kernel with HIP events (no graph), fills *_ms */
+    int64_t block_size;      /* Devex block size; 0 = auto (simplex_adaptive.py:89-96) */
+    int64_t price_lo;        /* arc shard [price_lo, price_hi) this handle prices; */
+    int64_t price_hi;        /*   both 0 = all arcs.  price_lo must be a multiple of 4. */
+    int32_t price_blocks;    /* pricing grid size; 0 = auto */
+    int32_t reserved;
+} mcf_options;
+
+typedef struct mcf_stats {
+    int64_t pivots;           /* FlowResult.iterations (degenerate pivots included) */
+    int64_t degenerate;       /* theta == 0 */
+    int64_t bound_flips;      /* leaving arc == entering arc */
+    int64_t arcs_priced;      /* sum over pricing passes of arcs whose rc was evaluated */
+    int64_t nodes_moved;      /* preorder positions rewritten by the apply pass */
+    int64_t subtree_nodes;    /* sum of re-hung subtree sizes */
+    int64_t cycle_arcs;       /* sum of cycle lengths */
+    int64_t batches;          /* host round trips */
+    int64_t unbounded_arc;    /* entering arc when status is MCF_ST_UNBOUNDED, else -1 */
+    int64_t unbounded_rc;     /* its reduced cost in the push direction (< 0) */
+    double solve_seconds;     /* wall time inside mcf_solve */
+    double price_ms;          /* with options.profile: summed kernel durations */
+    double pivot_ms;
+    double apply_ms;
+    int64_t price_launches;
+    int64_t pivot_launches;
+    int64_t apply_launches;
+    int64_t price_bytes;      /* algorithmic bytes of one pricing launch: 13 B/arc + 8 B/node (17 for Devex) */
+} mcf_stats;
+
+/* Called from mcf_solve every cb_interval pivots (simplex.py:1143-1154).
+ * Return non-zero to stop the solve (status becomes MCF_ST_ITERATION_LIMIT). */
+typedef int (*mcf_progress_cb)(void* user, int64_t pivots, int64_t max_pivots, double elapsed_seconds);
+
+/* Fill *opt with defaults. */
+void mcf_default_options(mcf_options* opt);
+
+/* Build the device-resident problem: arc SoA, potentials, preorder spanning tree with the
+ * all-artificial start basis.  n = real nodes (ids 0..n-1), m = arcs, lower bounds already
+ * shifted out.  cap[i] < 0 or >= 2^60 means uncapacitated.  sum(supply) must be 0.
+ * |cost| must fit int32 and m + n must stay below 2^30. */
+int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, const int64_t* cost,
+               const int64_t* cap, const int64_t* supply, const mcf_options* opt, mcf_handle** out);
+
+/* Pivot until optimal / unbounded / max_pivots more pivots were made (max_pivots < 0:
+ * the reference's default budget max(100, 20 * (m + n)), simplex.py:1470). */
+int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user, int64_t cb_interval);
+
+/* Copy the solution out.  Any pointer may be NULL.  objective_hi_lo[0..1] = high and low
+ * 64 bits of the exact 128-bit sum(flow*cost); flow[m]; potential[n] (root excluded);
+ * in_tree[m]. */
+int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int64_t* flow,
+                   int64_t* potential, int8_t* in_tree, mcf_stats* stats);
+
+/* One pricing pass over arcs [start, end) with the current potentials, without pivoting:
+ * the kernel-level parity hook.  *arc = -1 when no arc is eligible; *dir = +1 forward /
+ * -1 backward; *key = violation |rc| (Dantzig) or the f64 merit's bit pattern (Devex). */
+int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int64_t* arc, int32_t* dir,
+                   int64_t* key);
+
+/* Back to the all-artificial start basis (flows, potentials, tree, counters). */
+int mcf_reset(mcf_handle* h);
+
+/* ---- arc-sharded multi-GPU pivoting: one handle per rank, every rank holds the full
+ * replicated state and prices only its shard (options.price_lo/hi).  Per pivot:
+ *   mcf_enqueue_price   local best candidate -> cand_out (device, 2 x int64: key, arc)
+ *   <RCCL all-gather of the 16-byte candidates, by the caller, on the same stream>
+ *   mcf_enqueue_pivot   every rank applies the same winning pivot to its replica
+ * `stream` is a hipStream_t (0 = default stream).  Nothing here synchronises. */
+int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev);
+int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int32_t ncand);
+/* Read the control block (synchronises `stream`): status (MCF_ST_* or -1 = still running). */
+int mcf_poll(mcf_handle* h, void* stream, int32_t* status_or_running, int64_t* pivots);
+int mcf_set_max_pivots(mcf_handle* h, int64_t max_total_pivots);
+
+/* ---- measurement helpers (bench.py) */
+/* Launch the pricing kernel `reps` times back to back on the engine stream between two HIP
+ * events; *ms_per_launch = average duration.  Read-only with respect to the solver state. */
+int mcf_time_pricing(mcf_handle* h, int32_t rule, int32_t reps, double* ms_per_launch);
+/* Device-to-device copy of `bytes` bytes, `reps` times, between two HIP events: the measured
+ * HBM copy ceiling quoted beside the datasheet peak. */
+int mcf_time_copy(int32_t device, int64_t bytes, int32_t reps, double* ms_per_copy);
+
+/* ---- introspection for the parity tests: raw tree state, host copies.
+ * parent[n+1], pred_arc[n+1] (-1 for the root), size[n+1], pos[n+1], order[n+1], state[m]. */
+int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
+                 int32_t* order, int8_t* state, int64_t* potential_with_root);
+
+const char* mcf_last_error(mcf_handle* h); /* NULL handle: last create-time error of this thread */
+void mcf_destroy(mcf_handle* h);
+int mcf_abi_version(void);
+/* Number of usable HIP devices (0 when none); never initialises a context. */
+int mcf_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCF_H */

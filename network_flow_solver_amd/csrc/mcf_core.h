@@ -1,0 +1,366 @@
+// mcf_core.h -- data layout and per-pivot logic of the MI355X network-simplex engine.
+//
+// Everything here is integer and deterministic.  The functions are
+// __host__ __device__ so that (a) the HIP kernels in mcf_engine.hip and (b) the
+// host-only emulation build used by the CPU test-suite (oracle/emul_engine.cpp,
+// test infrastructure) execute the very same pivot logic.
+//
+// Reference path being replaced (file:line under /root/reference/src/network_solver/):
+//   reduced cost / eligibility ....... simplex.py:498-512, simplex_pricing.py:110-137
+//   cycle + ratio test ............... basis.py:178-241, simplex.py:1198-1229
+//   flow update ...................... simplex.py:1255-1283
+//   basis swap + tree/potential ...... simplex.py:1285-1425, basis.py:82-122
+//
+// Design differences from the reference (SURVEY.md section 8a "Native:" notes):
+//   * int64 flows/potentials, single-phase big-M start instead of two float phases;
+//   * a strongly feasible spanning tree (leaving-arc tie rule below) replaces the
+//     1e-10 * 1.00001^idx cost perturbation as the anti-cycling device;
+//   * the spanning tree is stored as a PREORDER ARRAY: order[pos] = node, and the
+//     subtree of v is the contiguous slice order[pos[v] .. pos[v]+size[v]).  A basis
+//     swap re-hangs one subtree; that becomes a block permutation of `order`
+//     (apply_map below) which, like the potential update of the moved subtree, is a
+//     data-parallel pass over a contiguous range -- no per-pivot BFS
+//     (basis.py:89-122) and no sequential thread-list walk.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MCF_HD __host__ __device__ __forceinline__
+#else
+#define MCF_HD inline
+#endif
+
+#define MCF_INF ((int64_t)1 << 60)  // "uncapacitated" sentinel; also ratio-test infinity
+
+enum McfStatus : int32_t {
+    MCF_RUNNING = 0,
+    MCF_OPTIMAL = 1,        // no eligible arc left
+    MCF_PIVOT_LIMIT = 2,    // max_pivots reached
+    MCF_UNBOUNDED = 3,      // ratio test found no blocking arc
+    MCF_INTERNAL_ERROR = 4
+};
+
+enum McfRule : int32_t { MCF_RULE_DANTZIG = 0, MCF_RULE_DEVEX_BLOCK = 1 };
+
+// One 16-byte record per node: a cycle walk needs exactly one load per step.
+struct alignas(16) McfNode {
+    int32_t parent;  // parent node (root: -1)
+    int32_t pred;    // (tree arc to parent << 1) | up, up = 1 when tail[arc] == this node
+    int32_t size;    // nodes in the subtree rooted here (>= 1)
+    int32_t pos;     // index of this node in the preorder array
+};
+
+// Walk-side arc data, 16 bytes: residuals of a cycle arc come from one load.
+struct alignas(16) McfArcW {
+    int64_t cap;   // MCF_INF when uncapacitated
+    int64_t flow;
+};
+
+// Entering-arc candidate: larger key wins, ties -> smaller arc index.
+struct alignas(16) McfCand {
+    int64_t key;   // Dantzig: violation = -state*rc > 0;  Devex: bit pattern of the f64 merit;  <= 0: none
+    int64_t arc;   // global arc index, -1 when none
+};
+
+// Segment of the block permutation that re-roots the moved subtree:
+// new positions [dst, dst+len) take old positions [src, src+len).
+struct McfSeg {
+    int32_t dst, src, len;
+};
+
+// Per-solve control block in device memory; the host only reads it between batches.
+struct McfCtx {
+    // ---- read by the host between batches
+    int32_t status;
+    int32_t unbounded_arc;
+    int64_t pivots;            // completed pivots (degenerate ones included, as the reference counts them)
+    int64_t degenerate;        // pivots with theta == 0
+    int64_t bound_flips;       // pivots whose leaving arc is the entering arc (tree unchanged)
+    int64_t max_pivots;
+    int64_t arcs_priced;       // sum of arcs whose reduced cost was evaluated
+    int64_t nodes_moved;       // sum of preorder positions rewritten (diagnostic)
+    int64_t subtree_nodes;     // sum of |T2| (diagnostic)
+    int64_t cycle_arcs;        // sum of cycle lengths (diagnostic)
+    // ---- block-search state (Devex rule)
+    int64_t block_size;
+    int64_t block_start;       // first arc of the block the next pricing pass scans
+    int32_t empty_blocks;      // consecutive blocks without a candidate
+    int32_t num_blocks;
+    // ---- preorder double buffer
+    int32_t cur;               // which order[] copy is current
+    int32_t pending_flip;      // the last apply wrote order[cur^1]; flip before the next pivot
+    int32_t prev_lo, prev_hi;  // range order[cur^1] is stale on
+    // ---- descriptor of the tree update the apply pass has to perform
+    int32_t apply;             // 0 = nothing, 1 = re-hang
+    int32_t lo, hi;            // affected preorder range
+    int32_t t2_old, t2_new, t2_size;  // old start a, new start b, |T2|
+    int32_t nseg;              // entries in seg[] (sorted by dst, cover [t2_new, t2_new+t2_size))
+    int64_t sigma;             // potential shift of the moved subtree
+};
+
+// Raw views the core functions operate on (device pointers in the kernels,
+// host pointers in the emulation build).
+struct McfView {
+    int32_t n_nodes;        // including the artificial root (= n_nodes - 1)
+    int64_t m;              // real arcs; artificial arc of node v is m + v
+    const int32_t* tail;    // [m_pad]
+    const int32_t* head;    // [m_pad]
+    const int32_t* cost;    // [m_pad]
+    int8_t* state;          // [m_pad]  +1 at lower bound, -1 at upper bound, 0 basic / padding
+    float* weight;          // [m_pad]  Devex reference weights (nullptr for Dantzig)
+    McfArcW* arcw;          // [m + n_nodes - 1]
+    int64_t* pi;            // [n_nodes]
+    McfNode* node;          // [n_nodes]
+    int32_t* order[2];      // [n_nodes] each
+    int32_t* path1;         // [n_nodes] scratch: nodes on the `first` side of the cycle
+    int32_t* path2;         // [n_nodes] scratch: nodes on the `second` side
+    McfSeg* seg;            // [2*n_nodes + 2] scratch
+    McfCtx* ctx;
+};
+
+MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc) {
+    return key > bkey || (key == bkey && key > 0 && arc < barc);
+}
+
+// Reduced cost of arc i under the current potentials (simplex.py:508-512):
+// rc = cost + pi[tail] - pi[head].  An arc is eligible when state * rc < 0
+// (simplex_pricing.py:124-131 with residuals expressed through `state`).
+MCF_HD int64_t mcf_violation(const McfView& v, int64_t i) {
+    const int64_t rc = (int64_t)v.cost[i] + v.pi[v.tail[i]] - v.pi[v.head[i]];
+    return -(int64_t)v.state[i] * rc;
+}
+
+// ---------------------------------------------------------------------------
+// The sequential part of one pivot: executed by ONE thread.
+//
+// Input: the winning candidate (already reduced over blocks / ranks).
+// Work:  O(cycle length) dependent loads -- join search by subtree size, ratio
+//        test with the strongly-feasible tie rule, flow augmentation, state
+//        swap, re-parenting of the stem, subtree-size bookkeeping, and the
+//        descriptor (segments, ranges, sigma) for the data-parallel apply pass.
+// ---------------------------------------------------------------------------
+MCF_HD void mcf_pivot_seq(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
+    McfCtx* c = v.ctx;
+    c->apply = 0;
+    if (c->pending_flip) {  // the previous apply pass wrote order[cur ^ 1]
+        c->cur ^= 1;
+        c->prev_lo = c->lo;
+        c->prev_hi = c->hi;
+        c->pending_flip = 0;
+    }
+    if (c->pivots >= c->max_pivots) { c->status = MCF_PIVOT_LIMIT; return; }
+
+    if (best_arc < 0 || best_key <= 0) {
+        if (rule == MCF_RULE_DEVEX_BLOCK) {
+            // this block held no eligible arc: move on (simplex_pricing.py:325-355)
+            c->empty_blocks += 1;
+            c->block_start += c->block_size;
+            if (c->block_start >= v.m) c->block_start = 0;
+            if (c->empty_blocks >= c->num_blocks) c->status = MCF_OPTIMAL;
+        } else {
+            c->status = MCF_OPTIMAL;
+        }
+        return;
+    }
+    c->empty_blocks = 0;
+
+    const int32_t e = (int32_t)best_arc;
+    const int32_t s = v.state[e];  // +1: flow rises from 0; -1: flow falls from cap
+    const int32_t first = s > 0 ? v.tail[e] : v.head[e];
+    const int32_t second = s > 0 ? v.head[e] : v.tail[e];
+    // exact reduced cost of the entering arc (the Devex key is a merit, not a violation)
+    const int64_t rc = (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
+
+    // --- join search + ratio test (basis.py:207-241, simplex.py:1201-1229).
+    // Flow is pushed second -> join -> first -> (entering arc) -> second.
+    // Tie rule for a strongly feasible tree: of all blocking arcs take the LAST one
+    // met on that route starting from the join, i.e. first-side arcs lose ties to
+    // the entering arc, which loses ties to second-side arcs.
+    int32_t u = first, w = second;
+    McfNode ru = v.node[u], rw = v.node[w];
+    int64_t d1 = MCF_INF, d2 = MCF_INF;
+    int32_t q1 = -1, q2 = -1, n1 = 0, n2 = 0;
+    while (u != w) {
+        if (ru.size < rw.size) {
+            const McfArcW a = v.arcw[ru.pred >> 1];
+            // first side is walked against the flow: an up arc loses flow, a down arc gains
+            const int64_t r = (ru.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
+            if (r < d1) { d1 = r; q1 = u; }
+            v.path1[n1++] = u;
+            u = ru.parent;
+            ru = v.node[u];
+        } else {
+            const McfArcW a = v.arcw[rw.pred >> 1];
+            const int64_t r = (rw.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
+            if (r <= d2) { d2 = r; q2 = w; }
+            v.path2[n2++] = w;
+            w = rw.parent;
+            rw = v.node[w];
+        }
+    }
+    const McfArcW ae = v.arcw[e];
+    const int64_t de = ae.cap;  // residual of the entering arc in its push direction
+    int32_t result, q;
+    int64_t delta;
+    if (d2 <= de && d2 <= d1) { result = 2; delta = d2; q = q2; }
+    else if (de <= d1) { result = 0; delta = de; q = -1; }
+    else { result = 1; delta = d1; q = q1; }
+
+    if (delta >= MCF_INF) {  // simplex.py:1231-1246
+        c->status = MCF_UNBOUNDED;
+        c->unbounded_arc = e;
+        return;
+    }
+
+    // --- flow update along the cycle (simplex.py:1255-1283)
+    if (delta > 0) {
+        v.arcw[e].flow = ae.flow + (int64_t)s * delta;
+        for (int32_t k = 0; k < n1; ++k) {
+            const int32_t p = v.node[v.path1[k]].pred;
+            v.arcw[p >> 1].flow += (p & 1) ? -delta : delta;
+        }
+        for (int32_t k = 0; k < n2; ++k) {
+            const int32_t p = v.node[v.path2[k]].pred;
+            v.arcw[p >> 1].flow += (p & 1) ? delta : -delta;
+        }
+    } else {
+        c->degenerate += 1;
+    }
+    c->pivots += 1;
+    c->cycle_arcs += n1 + n2 + 1;
+    if (v.weight) {  // Devex: only the selected arc's weight is refreshed (simplex_pricing.py:271-292);
+        // ||B^-1 a||^2 of a tree basis = number of tree arcs between the end points
+        const int32_t len = n1 + n2;
+        v.weight[e] = (float)(len > 0 ? len : 1);
+    }
+
+    if (result == 0) {  // entering arc is also the leaving arc (simplex.py:1320-1334)
+        v.state[e] = (int8_t)(-s);
+        c->bound_flips += 1;
+        return;
+    }
+
+    // --- basis swap (simplex.py:1335-1425), tree part only
+    const int32_t* stem = result == 1 ? v.path1 : v.path2;   // stem[0] = u_in ... stem[k] = q
+    const int32_t nstem_side = result == 1 ? n1 : n2;
+    const int32_t* other = result == 1 ? v.path2 : v.path1;  // other[0] = v_in ... (join excluded)
+    const int32_t nother = result == 1 ? n2 : n1;
+    const int32_t v_in = result == 1 ? second : first;
+    const int32_t leave = v.node[q].pred >> 1;
+    v.state[e] = 0;
+    if (leave < v.m) v.state[leave] = v.arcw[leave].flow == 0 ? (int8_t)1 : (int8_t)-1;
+
+    // potential shift that zeroes the entering arc's reduced cost
+    const bool tail_in_t2 = (result == 1) == (s > 0);
+    c->sigma = tail_in_t2 ? -rc : rc;
+
+    const McfNode rq = v.node[q];
+    const int32_t S = rq.size, a0 = rq.pos;
+    const McfNode rvin = v.node[v_in];
+
+    // insertion point in OLD coordinates: directly behind v_in, or at the end of
+    // v_in's block -- whichever moves fewer array elements
+    const int32_t tA = rvin.pos + 1, tB = rvin.pos + rvin.size;
+    const int32_t costA = tA <= a0 ? a0 - tA : tA - (a0 + S);
+    const int32_t costB = tB <= a0 ? a0 - tB : tB - (a0 + S);
+    const int32_t t = costA <= costB ? tA : tB;
+    const int32_t b = t <= a0 ? t : t - S;
+    c->t2_old = a0;
+    c->t2_new = b;
+    c->t2_size = S;
+    c->lo = t < a0 ? t : a0;
+    c->hi = t > a0 + S ? t : a0 + S;
+
+    // subtree sizes outside T2: the old ancestors of q lose S, v_in and its ancestors gain S
+    // (join and above keep their size)
+    int32_t k = 0;
+    while (stem[k] != q) ++k;
+    for (int32_t i = k + 1; i < nstem_side; ++i) v.node[stem[i]].size -= S;
+    for (int32_t i = 0; i < nother; ++i) v.node[other[i]].size += S;
+
+    // re-root T2 at u_in: reverse the stem, and emit the block permutation.
+    // Old layout: block(s_i) = [p_i, p_i + z_i), nested, s_k = q.
+    // New layout: block(s_0), then for i = 1..k: s_i + what precedes block(s_{i-1}) inside
+    // block(s_i), then what follows it.
+    int32_t nseg = 0;
+    int32_t prev_node = v_in, prev_pred = (e << 1) | (tail_in_t2 ? 1 : 0);
+    int32_t p_prev = 0, z_prev = 0, out = b;
+    for (int32_t i = 0; i <= k; ++i) {
+        const int32_t sn = stem[i];
+        const McfNode r = v.node[sn];
+        McfNode nr;
+        nr.parent = prev_node;
+        nr.pred = prev_pred;
+        nr.pos = r.pos;  // rewritten by the apply pass
+        if (i == 0) {
+            nr.size = S;
+            v.seg[nseg++] = McfSeg{out, r.pos, r.size};
+            out += r.size;
+        } else {
+            nr.size = S - z_prev;  // all of T2 except what stays below s_{i-1}
+            const int32_t left = p_prev - r.pos;                            // s_i itself + blocks before block(s_{i-1})
+            const int32_t right = (r.pos + r.size) - (p_prev + z_prev);    // blocks after it
+            v.seg[nseg++] = McfSeg{out, r.pos, left};
+            out += left;
+            if (right > 0) {
+                v.seg[nseg++] = McfSeg{out, p_prev + z_prev, right};
+                out += right;
+            }
+        }
+        // the arc s_i used to hang on now carries s_{i+1}; its direction bit flips
+        prev_pred = r.pred ^ 1;
+        prev_node = sn;
+        p_prev = r.pos;
+        z_prev = r.size;
+        v.node[sn] = nr;
+    }
+    c->nseg = nseg;
+    c->apply = 1;
+    c->pending_flip = 1;
+    c->subtree_nodes += S;
+    c->nodes_moved += c->hi - c->lo;
+    if (out != b + S) c->status = MCF_INTERNAL_ERROR;
+#if defined(MCF_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
+    if (out != b + S) {
+        fprintf(stderr, "pivot %lld: e=%d s=%d result=%d q=%d S=%d a0=%d t=%d b=%d out=%d k=%d n1=%d n2=%d v_in=%d\n",
+                (long long)c->pivots, e, s, result, q, S, a0, t, b, out, k, n1, n2, v_in);
+        for (int32_t i = 0; i < nseg; ++i) fprintf(stderr, "  seg dst=%d src=%d len=%d\n", v.seg[i].dst, v.seg[i].src, v.seg[i].len);
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// Data-parallel apply pass: new preorder position j  ->  old position.
+// Valid for j in [ctx.lo, ctx.hi).
+// ---------------------------------------------------------------------------
+MCF_HD int32_t mcf_apply_source(const McfCtx& c, const McfSeg* seg, int32_t j, bool* in_t2) {
+    const int32_t b = c.t2_new, S = c.t2_size, a0 = c.t2_old;
+    if (j >= b && j < b + S) {
+        *in_t2 = true;
+        int32_t lo = 0, hi = c.nseg - 1;  // last segment with dst <= j
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (seg[mid].dst <= j) lo = mid; else hi = mid - 1;
+        }
+        return seg[lo].src + (j - seg[lo].dst);
+    }
+    *in_t2 = false;
+    // untouched nodes slide over the gap T2 leaves behind
+    return b <= a0 ? j - S : j + S;
+}
+
+// One element of the apply pass (the HIP kernel runs this for a grid-strided j).
+MCF_HD void mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
+    const int32_t* src = v.order[c.cur];
+    int32_t* dst = v.order[c.cur ^ 1];
+    if (j >= c.lo && j < c.hi) {
+        bool in_t2;
+        const int32_t i = mcf_apply_source(c, v.seg, j, &in_t2);
+        const int32_t nd = src[i];
+        dst[j] = nd;
+        v.node[nd].pos = j;
+        if (in_t2) v.pi[nd] += c.sigma;
+    } else {
+        dst[j] = src[j];  // catch up on what the previous apply changed in the other copy
+    }
+}

@@ -1,0 +1,121 @@
+// mcf_host.h -- host-side problem staging shared by the HIP engine (mcf_engine.hip)
+// and the CPU emulation build used by the test-suite (oracle/emul_engine.cpp).
+//
+// Restates, in integer form, the set-up half of NetworkSimplex.__init__
+// (/root/reference/src/network_solver/simplex.py):
+//   _build_vectorized_arrays  :434-456  -> arc SoA (tail, head, cost, state) + walk records
+//   penalty cost              :161-163  -> big-M for artificial arcs
+//   _initialize_tree          :619-730  -> one artificial root arc per node, all basic
+//   basis.rebuild             basis.py:82-122 -> parent/pred/size/pos/order + potentials
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mcf_core.h"
+
+struct McfHostImage {
+    int32_t n = 0;          // real nodes
+    int32_t n_nodes = 0;    // n + 1 (root = n)
+    int64_t m = 0;          // real arcs
+    int64_t m_pad = 0;      // m rounded up to a multiple of 1024 (padding arcs have state 0)
+    int64_t big_m = 0;
+    std::vector<int32_t> tail, head, cost;  // [m_pad]
+    std::vector<int64_t> cost64;            // [m] exact costs for the objective
+    std::vector<int8_t> state;              // [m_pad]
+    std::vector<float> weight;              // [m_pad]
+    std::vector<McfArcW> arcw;              // [m + n]
+    std::vector<int64_t> pi;                // [n_nodes]
+    std::vector<McfNode> node;              // [n_nodes]
+    std::vector<int32_t> order;             // [n_nodes]
+    std::vector<int64_t> supply;            // [n]
+};
+
+// Validate the caller's arrays and build the start basis.  Returns "" or an error text.
+inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, const int32_t* head,
+                                   const int64_t* cost, const int64_t* cap, const int64_t* supply,
+                                   McfHostImage& im, int* err_code) {
+    *err_code = -1;  // MCF_E_BAD_ARG
+    if (n < 1) return "n must be >= 1";
+    if (m < 0) return "m must be >= 0";
+    if (m > 0 && (!tail || !head || !cost || !cap)) return "null arc array";
+    if (!supply) return "null supply array";
+    if ((int64_t)n + m >= ((int64_t)1 << 30)) { *err_code = -5; return "m + n must stay below 2^30"; }
+    im.n = n;
+    im.n_nodes = n + 1;
+    im.m = m;
+    im.m_pad = ((m + 1023) / 1024) * 1024;
+    if (im.m_pad == 0) im.m_pad = 1024;
+    im.tail.assign(im.m_pad, 0);
+    im.head.assign(im.m_pad, 0);
+    im.cost.assign(im.m_pad, 0);
+    im.cost64.assign(m, 0);
+    im.state.assign(im.m_pad, 0);
+    im.weight.assign(im.m_pad, 1.0f);
+    im.arcw.assign(m + n, McfArcW{0, 0});
+    im.supply.assign(supply, supply + n);
+
+    int64_t max_abs_cost = 0, total = 0;
+    for (int32_t v = 0; v < n; ++v) total += supply[v];
+    if (total != 0) return "supplies do not balance";
+    for (int64_t i = 0; i < m; ++i) {
+        if (tail[i] < 0 || tail[i] >= n || head[i] < 0 || head[i] >= n) return "arc end point out of range";
+        if (tail[i] == head[i]) return "self-loop";
+        const int64_t c = cost[i];
+        if (c > INT32_MAX || c < -(int64_t)INT32_MAX) { *err_code = -5; return "|cost| must fit int32"; }
+        int64_t cp = cap[i];
+        if (cp < 0 || cp >= MCF_INF) cp = MCF_INF;
+        im.tail[i] = tail[i];
+        im.head[i] = head[i];
+        im.cost[i] = (int32_t)c;
+        im.cost64[i] = c;
+        im.state[i] = 1;  // every real arc starts non-basic at its lower bound (flow 0)
+        im.arcw[i] = McfArcW{cp, 0};
+        const int64_t ac = c < 0 ? -c : c;
+        if (ac > max_abs_cost) max_abs_cost = ac;
+    }
+    // big-M: any simple path costs < (n+1) * max|c|, so an artificial arc is never cheaper
+    // than a real detour (the reference uses max|c| * (n_nodes+1) as its penalty, simplex.py:163)
+    im.big_m = (max_abs_cost + 1) * ((int64_t)n + 2);
+    if (im.big_m >= ((int64_t)1 << 44)) { *err_code = -5; return "max|cost| * n too large for the big-M start"; }
+
+    const int32_t root = n;
+    im.pi.assign(im.n_nodes, 0);
+    im.node.assign(im.n_nodes, McfNode{-1, -1, 1, 0});
+    im.order.assign(im.n_nodes, 0);
+    im.node[root] = McfNode{-1, -1, im.n_nodes, 0};
+    im.order[0] = root;
+    for (int32_t v = 0; v < n; ++v) {
+        const int64_t a = m + v;
+        const int64_t s = supply[v];
+        // supply >= 0: arc v -> root carrying s (up arc); demand: root -> v carrying -s.
+        // Zero-flow tree arcs point at the root, so the start tree is strongly feasible.
+        const int32_t up = s >= 0 ? 1 : 0;
+        im.arcw[a] = McfArcW{MCF_INF, s >= 0 ? s : -s};
+        im.pi[v] = up ? -im.big_m : im.big_m;
+        im.node[v] = McfNode{root, (int32_t)((a << 1) | up), 1, v + 1};
+        im.order[v + 1] = v;
+    }
+    *err_code = 0;
+    return "";
+}
+
+struct McfHostResult {
+    int32_t status = 0;        // MCF_ST_* numbering of include/mcf.h
+    __int128 objective = 0;
+    int64_t artificial_flow = 0;
+};
+
+// simplex.py:1573-1624 (infeasible when an artificial arc still carries flow) and
+// simplex.py:1703-1728 (objective over the original costs).
+inline void mcf_extract(const McfHostImage& im, const std::vector<McfArcW>& arcw, int32_t core_status,
+                        McfHostResult& r) {
+    r.artificial_flow = 0;
+    for (int32_t v = 0; v < im.n; ++v) r.artificial_flow += arcw[im.m + v].flow;
+    r.objective = 0;
+    for (int64_t i = 0; i < im.m; ++i) r.objective += (__int128)arcw[i].flow * (__int128)im.cost64[i];
+    if (core_status == MCF_UNBOUNDED) r.status = 3;
+    else if (core_status == MCF_OPTIMAL) r.status = r.artificial_flow > 0 ? 1 : 0;
+    else r.status = 2;
+}

@@ -1,0 +1,326 @@
+"""oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes front end of ``oracle/ref_simplex.c``, the CPU restatement of the
+reference's network-simplex path.  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg import this package; nothing under
+``network_flow_solver_amd/`` does.
+
+Parity pin: every fixture in ``tests/golden/`` was produced by running the
+reference itself (``tests/golden/make_golden.py``) and
+``tests/test_oracle_golden.py`` checks this oracle against all of them
+(status, objective, flows; Dantzig iteration counts too).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "libref_simplex.so"
+_SRC_PATH = _HERE / "ref_simplex.c"
+
+STRATEGIES = {"dantzig": 0, "devex": 1, "candidate_list": 2, "adaptive": 3}
+STATUS_NAMES = {0: "optimal", 1: "infeasible", 2: "iteration_limit", 3: "unbounded"}
+
+
+def build(force: bool = False) -> Path:
+    """Compile the C restatement with gcc (seconds)."""
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < _SRC_PATH.stat().st_mtime:
+        cmd = ["gcc", "-O2", "-std=gnu11", "-D_GNU_SOURCE", "-fPIC", "-shared",
+               "-o", str(_LIB_PATH), str(_SRC_PATH), "-lm"]
+        subprocess.run(cmd, check=True, cwd=str(_HERE))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = ctypes.CDLL(str(_LIB_PATH))
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        f64p = ctypes.POINTER(ctypes.c_double)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        lib.ref_solve.restype = ctypes.c_int
+        lib.ref_solve.argtypes = [
+            ctypes.c_int, ctypes.c_int64, i32p, i32p, f64p, f64p, f64p, f64p, ctypes.c_double,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            ctypes.POINTER(ctypes.c_int), f64p, f64p, f64p, u8p, i64p,
+        ]
+        lib.ref_price_dantzig.restype = ctypes.c_int64
+        lib.ref_price_dantzig.argtypes = [
+            ctypes.c_int64, i32p, i32p, f64p, f64p, f64p, f64p, u8p, ctypes.c_double, ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int),
+        ]
+        _lib = lib
+    return _lib
+
+
+def _ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+@dataclass
+class OracleResult:
+    status: str
+    objective: float
+    flows: dict = field(default_factory=dict)  # (tail_id, head_id) -> flow, reference post-processing applied
+    iterations: int = 0
+    duals: dict = field(default_factory=dict)
+    degenerate_pivots: int = 0
+    arcs_priced: int = 0
+    arc_flow: np.ndarray | None = None  # per input arc (reference internal order), flow + shift
+    unbounded_arc: tuple | None = None
+    solve_seconds: float = 0.0
+
+
+def solve_arrays(
+    n: int,
+    tail1: np.ndarray,
+    head1: np.ndarray,
+    cost: np.ndarray,
+    cap: np.ndarray,
+    lower: np.ndarray | None,
+    supply: np.ndarray,
+    tolerance: float = 1e-6,
+    strategy: str = "dantzig",
+    use_vectorized_pricing: bool = True,
+    block_size: int | None = None,
+    max_iterations: int | None = None,
+    pivot_budget: int | None = None,
+):
+    """Raw call: nodes 1..n (0 is the root), arcs in reference-internal order.
+
+    Returns (status, objective, flow[m], potential[n+1], in_tree[m], stats[5], seconds).
+    """
+    import time
+
+    lib = _load()
+    m = int(tail1.shape[0])
+    tail1 = np.ascontiguousarray(tail1, dtype=np.int32)
+    head1 = np.ascontiguousarray(head1, dtype=np.int32)
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    cap = np.ascontiguousarray(cap, dtype=np.float64)
+    lower_a = np.ascontiguousarray(lower if lower is not None else np.zeros(m), dtype=np.float64)
+    supply = np.ascontiguousarray(supply, dtype=np.float64)
+    assert supply.shape[0] == n
+    status = ctypes.c_int(0)
+    objective = ctypes.c_double(0.0)
+    flow = np.zeros(max(m, 1), dtype=np.float64)
+    pot = np.zeros(n + 1, dtype=np.float64)
+    in_tree = np.zeros(max(m, 1), dtype=np.uint8)
+    stats = np.zeros(8, dtype=np.int64)
+    t0 = time.perf_counter()
+    rc = lib.ref_solve(
+        n, m, _ptr(tail1, ctypes.c_int32), _ptr(head1, ctypes.c_int32), _ptr(cost, ctypes.c_double),
+        _ptr(cap, ctypes.c_double), _ptr(lower_a, ctypes.c_double), _ptr(supply, ctypes.c_double),
+        float(tolerance), STRATEGIES[strategy], 1 if use_vectorized_pricing else 0,
+        int(block_size) if block_size else 0,
+        -1 if max_iterations is None else int(max_iterations),
+        -1 if pivot_budget is None else int(pivot_budget),
+        ctypes.byref(status), ctypes.byref(objective), _ptr(flow, ctypes.c_double),
+        _ptr(pot, ctypes.c_double), _ptr(in_tree, ctypes.c_uint8), _ptr(stats, ctypes.c_int64),
+    )
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError(f"ref_solve failed with code {rc}")
+    return status.value, objective.value, flow[:m], pot, in_tree[:m], stats, dt
+
+
+def solve_dicts(
+    nodes: list[dict],
+    arcs: list[dict],
+    directed: bool = True,
+    tolerance: float = 1e-6,
+    strategy: str = "dantzig",
+    max_iterations: int | None = None,
+    **kw,
+) -> OracleResult:
+    """Solve a reference-style problem description the way the reference would.
+
+    Mirrors ``NetworkSimplex.__init__`` ordering: node ids sorted as strings
+    (simplex.py:149), arcs sorted by (tail, head) strings (simplex.py:395),
+    undirected edges expanded to lower = -capacity (data.py:162-223).
+    """
+    ids = sorted(str(nd["id"]) for nd in nodes)
+    index = {nid: i + 1 for i, nid in enumerate(ids)}
+    supply = np.zeros(len(ids), dtype=np.float64)
+    for nd in nodes:
+        supply[index[str(nd["id"])] - 1] = float(nd.get("supply", 0.0))
+    recs = []
+    for a in arcs:
+        capv = a.get("capacity")
+        lowerv = float(a.get("lower", 0.0))
+        if not directed:
+            lowerv = -float(capv)
+        recs.append((str(a["tail"]), str(a["head"]), float(a.get("cost", 0.0)),
+                     math.inf if capv is None else float(capv), lowerv))
+    recs.sort(key=lambda r: (r[0], r[1]))  # stable, like list.sort in the reference
+    m = len(recs)
+    tail1 = np.array([index[r[0]] for r in recs], dtype=np.int32).reshape(m)
+    head1 = np.array([index[r[1]] for r in recs], dtype=np.int32).reshape(m)
+    cost = np.array([r[2] for r in recs], dtype=np.float64).reshape(m)
+    cap = np.array([r[3] for r in recs], dtype=np.float64).reshape(m)
+    lower = np.array([r[4] for r in recs], dtype=np.float64).reshape(m)
+    st, obj, flow, pot, in_tree, stats, dt = solve_arrays(
+        len(ids), tail1, head1, cost, cap, lower, supply, tolerance, strategy,
+        max_iterations=max_iterations, **kw)
+    status = STATUS_NAMES[st]
+    res = OracleResult(status=status, objective=float(round(obj, 12)), iterations=int(stats[0]),
+                       degenerate_pivots=int(stats[1]), arcs_priced=int(stats[2]), solve_seconds=dt)
+    if status == "unbounded":
+        ua = int(stats[3])
+        res.unbounded_arc = (recs[ua][0], recs[ua][1]) if 0 <= ua < m else None
+        return res
+    if stats[4]:  # infeasible / phase-1 iteration limit: FlowResult(objective=0.0, flows={}, duals={})
+        res.objective = 0.0
+        return res
+    flows: dict = {}
+    for i, r in enumerate(recs):  # simplex.py:1703-1721
+        key = (r[0], r[1])
+        flows[key] = flows.get(key, 0.0) + float(flow[i])
+    res.flows = {k: float(round(v, 12)) for k, v in flows.items() if abs(v) > tolerance}
+    res.duals = {nid: float(round(pot[index[nid]], 12)) for nid in ids}
+    res.arc_flow = flow
+    return res
+
+
+def solve_soa(inst, strategy: str = "dantzig", reference_order: bool = True, tolerance: float = 1e-6,
+              pivot_budget: int | None = None, **kw):
+    """Solve a generators.ArcSoA instance (DIMACS ids "1".."n").
+
+    ``reference_order=True`` applies the reference's string sort of node ids and
+    arc keys so pivots follow the reference; False keeps numeric order (cheaper
+    to set up for the 1M-node cpu_baseline sample; same optimum).
+    Returns dict(status, objective, iterations, arcs_priced, flow (input arc order), seconds).
+    """
+    n, m = inst.n, inst.m
+    if reference_order:
+        ids = np.array([str(v + 1) for v in range(n)])
+        order = np.argsort(ids, kind="stable")  # lexicographic, like sorted(str)
+        rank = np.empty(n, dtype=np.int64)
+        rank[order] = np.arange(n)
+        t_s, h_s = ids[inst.tail], ids[inst.head]
+        arc_order = np.lexsort((h_s, t_s))  # primary tail string, then head string; stable
+        node1 = rank + 1
+    else:
+        arc_order = np.arange(m)
+        node1 = np.arange(1, n + 1)
+    tail1 = node1[inst.tail[arc_order]].astype(np.int32)
+    head1 = node1[inst.head[arc_order]].astype(np.int32)
+    cap = inst.cap[arc_order].astype(np.float64)
+    cap[cap < 0] = np.inf
+    supply = np.zeros(n, dtype=np.float64)
+    supply[node1 - 1] = inst.supply.astype(np.float64)
+    st, obj, flow, pot, in_tree, stats, dt = solve_arrays(
+        n, tail1, head1, inst.cost[arc_order].astype(np.float64), cap, None, supply, tolerance, strategy,
+        pivot_budget=pivot_budget, **kw)
+    flow_in = np.empty(m, dtype=np.float64)
+    flow_in[arc_order] = flow
+    return {"status": STATUS_NAMES[st], "objective": float(round(obj, 12)), "iterations": int(stats[0]),
+            "degenerate_pivots": int(stats[1]), "arcs_priced": int(stats[2]), "flow": flow_in, "seconds": dt}
+
+
+def price_dantzig(tail, head, cost, potential, fwd_res, bwd_res, in_tree, tolerance=1e-6, allow_zero=False):
+    """One full-scan Dantzig pass (simplex_pricing.py:97-137). Returns (arc, dir) or None."""
+    lib = _load()
+    m = int(len(tail))
+    d = ctypes.c_int(0)
+    arc = lib.ref_price_dantzig(
+        m, _ptr(np.ascontiguousarray(tail, np.int32), ctypes.c_int32),
+        _ptr(np.ascontiguousarray(head, np.int32), ctypes.c_int32),
+        _ptr(np.ascontiguousarray(cost, np.float64), ctypes.c_double),
+        _ptr(np.ascontiguousarray(potential, np.float64), ctypes.c_double),
+        _ptr(np.ascontiguousarray(fwd_res, np.float64), ctypes.c_double),
+        _ptr(np.ascontiguousarray(bwd_res, np.float64), ctypes.c_double),
+        _ptr(np.ascontiguousarray(in_tree, np.uint8), ctypes.c_uint8),
+        float(tolerance), 1 if allow_zero else 0, ctypes.byref(d))
+    return None if arc < 0 else (int(arc), int(d.value))
+
+
+# ---------------------------------------------------------------------------
+# CPU emulation of the HIP engine's own pivot algorithm (oracle/emul_engine.cpp).
+# Same headers as the kernels, scalar loops instead of kernels.  Test-only.
+# ---------------------------------------------------------------------------
+_EMUL_LIB_PATH = _HERE / "libmcf_emul.so"
+_EMUL_SRC = _HERE / "emul_engine.cpp"
+_CORE_HEADERS = [
+    _HERE.parent / "network_flow_solver_amd" / "csrc" / "mcf_core.h",
+    _HERE.parent / "network_flow_solver_amd" / "csrc" / "mcf_host.h",
+]
+
+
+def build_emul(force: bool = False) -> Path:
+    newest = max(p.stat().st_mtime for p in [_EMUL_SRC, *_CORE_HEADERS])
+    if force or not _EMUL_LIB_PATH.exists() or _EMUL_LIB_PATH.stat().st_mtime < newest:
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(_EMUL_LIB_PATH), str(_EMUL_SRC)]
+        subprocess.run(cmd, check=True, cwd=str(_HERE))
+    return _EMUL_LIB_PATH
+
+
+_emul = None
+
+
+def _load_emul():
+    global _emul
+    if _emul is None:
+        build_emul()
+        lib = ctypes.CDLL(str(_EMUL_LIB_PATH))
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        i8p = ctypes.POINTER(ctypes.c_int8)
+        lib.emul_solve.restype = ctypes.c_int
+        lib.emul_solve.argtypes = [
+            ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, ctypes.c_int32, ctypes.c_int64,
+            ctypes.c_int64, i32p, i64p, i64p, i64p, i8p, i64p, i32p, i32p, i32p, i32p, i32p, i64p, ctypes.c_int64,
+        ]
+        _emul = lib
+    return _emul
+
+
+def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0, max_pivots: int = -1,
+               trace: int = 0) -> dict:
+    """Run the engine's integer pivot algorithm on the CPU. Arrays are 0-based ints; cap < 0 = inf."""
+    lib = _load_emul()
+    m = int(len(tail))
+    tail = np.ascontiguousarray(tail, np.int32)
+    head = np.ascontiguousarray(head, np.int32)
+    cost = np.ascontiguousarray(cost, np.int64)
+    cap = np.ascontiguousarray(cap, np.int64)
+    supply = np.ascontiguousarray(supply, np.int64)
+    status = ctypes.c_int32(0)
+    obj = np.zeros(2, np.int64)
+    flow = np.zeros(max(m, 1), np.int64)
+    pot = np.zeros(n, np.int64)
+    in_tree = np.zeros(max(m, 1), np.int8)
+    stats = np.zeros(10, np.int64)
+    parent, pred, size, pos, order = (np.zeros(n + 1, np.int32) for _ in range(5))
+    tr = np.full(max(trace, 1), -2, np.int64)
+    rc = lib.emul_solve(
+        n, m, _ptr(tail, ctypes.c_int32), _ptr(head, ctypes.c_int32), _ptr(cost, ctypes.c_int64),
+        _ptr(cap, ctypes.c_int64), _ptr(supply, ctypes.c_int64), rule, block_size, max_pivots,
+        ctypes.byref(status), _ptr(obj, ctypes.c_int64), _ptr(flow, ctypes.c_int64), _ptr(pot, ctypes.c_int64),
+        _ptr(in_tree, ctypes.c_int8), _ptr(stats, ctypes.c_int64), _ptr(parent, ctypes.c_int32),
+        _ptr(pred, ctypes.c_int32), _ptr(size, ctypes.c_int32), _ptr(pos, ctypes.c_int32),
+        _ptr(order, ctypes.c_int32), _ptr(tr, ctypes.c_int64), trace)
+    if rc != 0:
+        raise RuntimeError(f"emul_solve failed with code {rc}")
+    objective = (int(obj[0]) << 64) + (int(obj[1]) & ((1 << 64) - 1))
+    return {
+        "status": STATUS_NAMES[status.value], "objective": objective, "flow": flow[:m], "potential": pot,
+        "in_tree": in_tree[:m], "pivots": int(stats[0]), "degenerate": int(stats[1]), "bound_flips": int(stats[2]),
+        "arcs_priced": int(stats[3]), "nodes_moved": int(stats[4]), "subtree_nodes": int(stats[5]),
+        "cycle_arcs": int(stats[6]), "unbounded_arc": int(stats[7]), "artificial_flow": int(stats[8]),
+        "seconds": stats[9] / 1e9, "parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order,
+        "trace": tr[:trace] if trace else None,
+    }

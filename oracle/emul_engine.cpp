@@ -1,0 +1,144 @@
+// oracle/emul_engine.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Host-only emulation of the HIP engine: the per-pivot logic comes from the very
+// headers the kernels are compiled from (network_flow_solver_amd/csrc/mcf_core.h,
+// mcf_host.h); the three kernels (pricing sweep, pivot, apply) are replaced by scalar
+// loops.  Purpose: (1) let the CPU-only test-suite exercise the preorder-tree pivot
+// algorithm against the reference-derived goldens without a GPU, (2) differential
+// testing on the GPU box -- the kernels must reproduce this pivot sequence exactly, so
+// any divergence is a parallelisation / memory-ordering bug, not an algorithm bug.
+//
+// The shipped library never links or loads this file.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "../network_flow_solver_amd/csrc/mcf_host.h"
+
+namespace {
+
+struct Emul {
+    McfHostImage im;
+    std::vector<int32_t> order1, path1, path2;
+    std::vector<McfSeg> seg;
+    McfCtx ctx;
+    McfView view;
+    int rule = 0;
+};
+
+void bind(Emul& e) {
+    McfHostImage& im = e.im;
+    e.order1 = im.order;
+    e.path1.assign(im.n_nodes, 0);
+    e.path2.assign(im.n_nodes, 0);
+    e.seg.assign(2 * (size_t)im.n_nodes + 2, McfSeg{0, 0, 0});
+    std::memset(&e.ctx, 0, sizeof e.ctx);
+    e.ctx.unbounded_arc = -1;
+    McfView& v = e.view;
+    v.n_nodes = im.n_nodes;
+    v.m = im.m;
+    v.tail = im.tail.data();
+    v.head = im.head.data();
+    v.cost = im.cost.data();
+    v.state = im.state.data();
+    v.weight = e.rule == MCF_RULE_DEVEX_BLOCK ? im.weight.data() : nullptr;
+    v.arcw = im.arcw.data();
+    v.pi = im.pi.data();
+    v.node = im.node.data();
+    v.order[0] = im.order.data();
+    v.order[1] = e.order1.data();
+    v.path1 = e.path1.data();
+    v.path2 = e.path2.data();
+    v.seg = e.seg.data();
+    v.ctx = &e.ctx;
+}
+
+// scalar stand-in for the pricing kernel
+void price(const Emul& e, int64_t lo, int64_t hi, int64_t* key, int64_t* arc) {
+    const McfView& v = e.view;
+    int64_t bk = 0, ba = -1;
+    for (int64_t i = lo; i < hi; ++i) {
+        if (!v.state[i]) continue;
+        const int64_t viol = mcf_violation(v, i);
+        if (viol <= 0) continue;
+        int64_t k = viol;
+        if (e.rule == MCF_RULE_DEVEX_BLOCK) {
+            const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
+            std::memcpy(&k, &merit, 8);
+        }
+        if (mcf_cand_better(k, i, bk, ba)) { bk = k; ba = i; }
+    }
+    *key = bk;
+    *arc = ba;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Returns 0 or a negative MCF_E_* code.  Outputs sized like mcf_get_result / mcf_get_tree.
+int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, const int64_t* cost,
+               const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int64_t max_pivots,
+               int32_t* status, int64_t* objective_hi_lo, int64_t* flow, int64_t* potential, int8_t* in_tree,
+               int64_t* stats /*[10]*/, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
+               int32_t* order, int64_t* trace_arcs, int64_t trace_cap) {
+    Emul e;
+    e.rule = rule;
+    int err = 0;
+    std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e.im, &err);
+    if (err) { std::fprintf(stderr, "emul_solve: %s\n", msg.c_str()); return err; }
+    bind(e);
+    McfCtx& c = e.ctx;
+    c.max_pivots = max_pivots < 0 ? (20 * (m + n) > 100 ? 20 * (m + n) : 100) : max_pivots;
+    if (block_size <= 0) block_size = m < 1000 ? m / 4 : (m < 10000 ? m / 8 : m / 16);  // simplex_adaptive.py:89-96
+    if (block_size < 1) block_size = 1;
+    c.block_size = rule == MCF_RULE_DEVEX_BLOCK ? block_size : (m > 0 ? m : 1);
+    c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
+    if (c.num_blocks < 1) c.num_blocks = 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    int64_t ntrace = 0;
+    while (c.status == MCF_RUNNING) {
+        int64_t lo = 0, hi = m;
+        if (rule == MCF_RULE_DEVEX_BLOCK) { lo = c.block_start; hi = lo + c.block_size < m ? lo + c.block_size : m; }
+        int64_t key, arc;
+        price(e, lo, hi, &key, &arc);
+        c.arcs_priced += hi - lo;
+        if (trace_arcs && ntrace < trace_cap) trace_arcs[ntrace++] = arc;
+        mcf_pivot_seq(e.view, key, arc, rule);
+        if (c.apply) {
+            // the two ranges the apply kernel covers: this pivot's and the stale one
+            for (int32_t j = c.lo; j < c.hi; ++j) mcf_apply_one(e.view, c, j);
+            for (int32_t j = c.prev_lo; j < c.prev_hi; ++j)
+                if (j < c.lo || j >= c.hi) mcf_apply_one(e.view, c, j);
+        }
+    }
+    if (c.pending_flip) { c.cur ^= 1; c.pending_flip = 0; }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    McfHostResult r;
+    mcf_extract(e.im, e.im.arcw, c.status, r);
+    if (c.status == MCF_INTERNAL_ERROR) return -7;
+    *status = r.status;
+    objective_hi_lo[0] = (int64_t)(r.objective >> 64);
+    objective_hi_lo[1] = (int64_t)(uint64_t)r.objective;
+    for (int64_t i = 0; i < m; ++i) {
+        if (flow) flow[i] = e.im.arcw[i].flow;
+        if (in_tree) in_tree[i] = e.im.state[i] == 0;
+    }
+    if (potential) for (int32_t v = 0; v < n; ++v) potential[v] = e.im.pi[v] - e.im.pi[n];
+    stats[0] = c.pivots; stats[1] = c.degenerate; stats[2] = c.bound_flips; stats[3] = c.arcs_priced;
+    stats[4] = c.nodes_moved; stats[5] = c.subtree_nodes; stats[6] = c.cycle_arcs; stats[7] = c.unbounded_arc;
+    stats[8] = r.artificial_flow; stats[9] = (int64_t)(secs * 1e9);
+    const int32_t* ord = e.view.order[c.cur];
+    for (int32_t v = 0; v <= n; ++v) {
+        if (parent) parent[v] = e.im.node[v].parent;
+        if (pred_arc) pred_arc[v] = e.im.node[v].pred < 0 ? -1 : e.im.node[v].pred >> 1;
+        if (size) size[v] = e.im.node[v].size;
+        if (pos) pos[v] = e.im.node[v].pos;
+        if (order) order[v] = ord[v];
+    }
+    return 0;
+}
+
+}  // extern "C"
