@@ -40,7 +40,11 @@ enum McfStatus : int32_t {
     MCF_INTERNAL_ERROR = 4
 };
 
-enum McfRule : int32_t { MCF_RULE_DANTZIG = 0, MCF_RULE_DEVEX_BLOCK = 1 };
+// pricing rules (same numbering as MCF_RULE_* in include/mcf.h)
+#define MCF_RULE_DANTZIG 0
+#ifndef MCF_RULE_DEVEX_BLOCK
+#define MCF_RULE_DEVEX_BLOCK 1
+#endif
 
 // One 16-byte record per node: a cycle walk needs exactly one load per step.
 struct alignas(16) McfNode {

@@ -1,0 +1,748 @@
+// mcf_engine.hip -- MI355X (gfx950) network-simplex pivot engine: HIP kernels + C ABI.
+//
+// One pivot = three kernels on one stream (no host round trip in between):
+//
+//   k_price   grid-wide reduced-cost sweep over the arc SoA: coalesced 16-byte loads of
+//             tail/head/cost (+4 state bytes), gathers of pi[tail], pi[head], per-lane
+//             best, wavefront xor-shuffle arg-max, one candidate per workgroup.
+//             HBM-bound: 13 B/arc (+4 B/arc Devex weight) + 8 B per distinct node.
+//             Replaces simplex.py:498-617 and simplex_pricing.py:97-137, 310-357.
+//   k_pivot   one workgroup: final arg-max over the workgroup candidates (or the candidates
+//             all-gathered from the other ranks), then ONE lane runs mcf_pivot_seq (join,
+//             ratio test, flow update, stem re-parenting; O(cycle) dependent loads).
+//             Replaces basis.py:178-241 and simplex.py:1198-1425.
+//   k_apply   grid-wide block permutation of the preorder array for the re-hung subtree +
+//             its potential shift (pi += sigma) + pos rewrite.  Replaces the per-pivot
+//             BFS rebuild (basis.py:82-122) and _update_tree_sets (simplex.py:1103-1107).
+//
+// The host enqueues `batch_pivots` pivots (optionally as one captured hipGraph), then
+// reads the 200-byte control block back once.  Kernels of a finished solve early-exit.
+//
+// gfx950 only; no CPU path: without a device every compute entry point returns
+// MCF_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mcf.h"
+#include "mcf_core.h"
+#include "mcf_host.h"
+
+namespace {
+
+constexpr int kPriceThreads = 256;
+constexpr int kPivotThreads = 256;
+constexpr int kApplyThreads = 256;
+constexpr int kMaxPriceBlocks = 2048;  // 8 workgroups per CU on 256 CUs
+constexpr int kMaxApplyBlocks = 512;
+
+thread_local std::string g_create_error;
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ void wave_argmax(int64_t& key, int64_t& arc) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int64_t ok = (int64_t)__shfl_xor((long long)key, off, 64);
+        const int64_t oa = (int64_t)__shfl_xor((long long)arc, off, 64);
+        if (mcf_cand_better(ok, oa, key, arc)) { key = ok; arc = oa; }
+    }
+}
+
+// Block-wide arg-max; result valid in thread 0.
+template <int THREADS>
+__device__ __forceinline__ void block_argmax(int64_t& key, int64_t& arc) {
+    __shared__ int64_t s_key[THREADS / 64];
+    __shared__ int64_t s_arc[THREADS / 64];
+    wave_argmax(key, arc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_key[wave] = key; s_arc[wave] = arc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < THREADS / 64; ++w)
+            if (mcf_cand_better(s_key[w], s_arc[w], key, arc)) { key = s_key[w]; arc = s_arc[w]; }
+    }
+}
+
+// ------------------------------------------------------------------ k_price
+// Each lane owns groups of 4 consecutive arcs (one 16-byte load per SoA stream).
+// range: [lo, hi) is this handle's shard; with USE_BLOCK the Devex block
+// [ctx.block_start, +block_size) is intersected with it on the device, so the host
+// never has to know where the block search currently stands.
+template <int RULE>
+__global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t lo, int64_t hi, int use_block,
+                                                          McfCand* __restrict__ cand) {
+    int64_t key = 0, arc = -1;
+    const McfCtx* c = v.ctx;
+    if (c->status == MCF_RUNNING) {
+        if (use_block) {
+            const int64_t bs = c->block_start, be = bs + c->block_size;
+            lo = lo > bs ? lo : bs;
+            hi = hi < be ? hi : be;
+        }
+        const int64_t g_lo = lo >> 2, g_hi = (hi + 3) >> 2;  // groups of 4 arcs
+        const int4* __restrict__ tail4 = reinterpret_cast<const int4*>(v.tail);
+        const int4* __restrict__ head4 = reinterpret_cast<const int4*>(v.head);
+        const int4* __restrict__ cost4 = reinterpret_cast<const int4*>(v.cost);
+        const int32_t* __restrict__ state4 = reinterpret_cast<const int32_t*>(v.state);
+        const float4* __restrict__ w4 = reinterpret_cast<const float4*>(v.weight);
+        const int64_t* __restrict__ pi = v.pi;
+        const int64_t stride = (int64_t)gridDim.x * kPriceThreads;
+        for (int64_t g = g_lo + (int64_t)blockIdx.x * kPriceThreads + threadIdx.x; g < g_hi; g += stride) {
+            const int32_t st = state4[g];
+            if (st == 0) continue;  // four basic / padding arcs: nothing to gather
+            const int4 t = tail4[g], h = head4[g], cc = cost4[g];
+            float4 w = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (RULE == MCF_RULE_DEVEX_BLOCK) w = w4[g];
+            const int32_t ts[4] = {t.x, t.y, t.z, t.w}, hs[4] = {h.x, h.y, h.z, h.w}, cs[4] = {cc.x, cc.y, cc.z, cc.w};
+            const float ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int32_t s = (int32_t)(int8_t)(st >> (8 * k));
+                const int64_t i = (g << 2) + k;
+                if (s == 0 || i < lo || i >= hi) continue;
+                const int64_t rc = (int64_t)cs[k] + pi[ts[k]] - pi[hs[k]];
+                const int64_t viol = -(int64_t)s * rc;
+                if (viol <= 0) continue;
+                int64_t kk = viol;
+                if (RULE == MCF_RULE_DEVEX_BLOCK) {
+                    const double merit = ((double)viol * (double)viol) / (double)ws[k];
+                    kk = __double_as_longlong(merit);
+                }
+                if (mcf_cand_better(kk, i, key, arc)) { key = kk; arc = i; }
+            }
+        }
+    }
+    block_argmax<kPriceThreads>(key, arc);
+    if (threadIdx.x == 0) cand[blockIdx.x] = McfCand{key, arc};
+}
+
+// ------------------------------------------------------------------ k_reduce (multi-GPU: local best -> 16 bytes)
+__global__ __launch_bounds__(kPivotThreads) void k_reduce(const McfCand* __restrict__ cand, int ncand,
+                                                           McfCand* __restrict__ out) {
+    int64_t key = 0, arc = -1;
+    for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
+        const McfCand cd = cand[i];
+        if (mcf_cand_better(cd.key, cd.arc, key, arc)) { key = cd.key; arc = cd.arc; }
+    }
+    block_argmax<kPivotThreads>(key, arc);
+    if (threadIdx.x == 0) *out = McfCand{key, arc};
+}
+
+// ------------------------------------------------------------------ k_pivot
+__global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView v, const McfCand* __restrict__ cand, int ncand,
+                                                          int32_t rule, int64_t priced_per_pass) {
+    if (v.ctx->status != MCF_RUNNING) {
+        if (threadIdx.x == 0) v.ctx->apply = 0;
+        return;
+    }
+    int64_t key = 0, arc = -1;
+    for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
+        const McfCand cd = cand[i];
+        if (mcf_cand_better(cd.key, cd.arc, key, arc)) { key = cd.key; arc = cd.arc; }
+    }
+    block_argmax<kPivotThreads>(key, arc);
+    if (threadIdx.x == 0) {
+        if (v.ctx->pivots < v.ctx->max_pivots) v.ctx->arcs_priced += priced_per_pass;
+        mcf_pivot_seq(v, key, arc, rule);
+    }
+}
+
+// ------------------------------------------------------------------ k_apply
+__global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
+    const McfCtx c = *v.ctx;  // uniform: scalar loads
+    if (!c.apply) return;
+    const int64_t stride = (int64_t)gridDim.x * kApplyThreads;
+    const int64_t tid = (int64_t)blockIdx.x * kApplyThreads + threadIdx.x;
+    for (int64_t j = c.lo + tid; j < c.hi; j += stride) mcf_apply_one(v, c, (int32_t)j);
+    // catch-up copy of what the previous apply changed in the other buffer
+    for (int64_t j = c.prev_lo + tid; j < c.prev_hi; j += stride)
+        if (j < c.lo || j >= c.hi) mcf_apply_one(v, c, (int32_t)j);
+}
+
+// ------------------------------------------------------------------ k_ctl: (re)arm the control block
+__global__ void k_ctl(McfCtx* c, int64_t max_pivots, int resume) {
+    c->max_pivots = max_pivots;
+    if (resume && c->status == MCF_PIVOT_LIMIT && c->pivots < max_pivots) c->status = MCF_RUNNING;
+}
+
+__global__ void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+}  // namespace
+
+// ====================================================================== handle
+struct mcf_handle {
+    McfHostImage im;
+    mcf_options opt{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // device arrays
+    int32_t *d_tail = nullptr, *d_head = nullptr, *d_cost = nullptr;
+    int8_t* d_state = nullptr;
+    float* d_weight = nullptr;
+    McfArcW* d_arcw = nullptr;
+    int64_t* d_pi = nullptr;
+    McfNode* d_node = nullptr;
+    int32_t *d_order0 = nullptr, *d_order1 = nullptr, *d_path1 = nullptr, *d_path2 = nullptr;
+    McfSeg* d_seg = nullptr;
+    McfCtx* d_ctx = nullptr;
+    McfCand* d_cand = nullptr;
+    McfCand* d_one = nullptr;
+    McfCtx* h_ctx = nullptr;   // pinned
+    McfCand* h_one = nullptr;  // pinned
+    McfView view{};
+    int price_blocks = 1;
+    int apply_blocks = 1;
+    int64_t price_lo = 0, price_hi = 0;
+    int64_t priced_per_pass = 0;
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_batch = 0;
+    // profiling events
+    std::vector<hipEvent_t> events;
+    // bookkeeping
+    mcf_stats stats{};
+    int64_t total_cap = 0;
+    std::string err;
+    bool solved_once = false;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                        \
+            return MCF_E_HIP;                                                                    \
+        }                                                                                        \
+    } while (0)
+
+int usable_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+template <typename T>
+hipError_t dalloc(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T)); }
+
+int upload_image(mcf_handle* h) {
+    const McfHostImage& im = h->im;
+    HIP_TRY(h, hipMemcpyAsync(h->d_tail, im.tail.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_head, im.head.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_cost, im.cost.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_state, im.state.data(), im.m_pad, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_weight, im.weight.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_arcw, im.arcw.data(), im.arcw.size() * sizeof(McfArcW), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_pi, im.pi.data(), im.pi.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_node, im.node.data(), im.node.size() * sizeof(McfNode), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_order0, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_order1, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
+    McfCtx c;
+    std::memset(&c, 0, sizeof c);
+    c.unbounded_arc = -1;
+    int64_t bs = h->opt.block_size;
+    const int64_t m = im.m;
+    if (bs <= 0) bs = m < 1000 ? m / 4 : (m < 10000 ? m / 8 : m / 16);  // simplex_adaptive.py:89-96
+    if (bs < 1) bs = 1;
+    c.block_size = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? bs : (m > 0 ? m : 1);
+    c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
+    if (c.num_blocks < 1) c.num_blocks = 1;
+    *h->h_ctx = c;
+    HIP_TRY(h, hipMemcpyAsync(h->d_ctx, h->h_ctx, sizeof(McfCtx), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // per-pass accounting: a Devex pass prices one block of the shard, Dantzig the whole shard
+    const int64_t shard = h->price_hi - h->price_lo;
+    h->priced_per_pass = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? (c.block_size < shard ? c.block_size : shard) : shard;
+    std::memset(&h->stats, 0, sizeof h->stats);
+    h->stats.unbounded_arc = -1;
+    h->stats.price_bytes = (h->opt.rule == MCF_RULE_DEVEX_BLOCK ? 17 : 13) * h->priced_per_pass + 8 * (int64_t)im.n_nodes;
+    h->total_cap = 0;
+    h->solved_once = false;
+    return MCF_OK;
+}
+
+void launch_price(mcf_handle* h, hipStream_t s, int32_t rule, int64_t lo, int64_t hi, int use_block) {
+    if (rule == MCF_RULE_DEVEX_BLOCK)
+        hipLaunchKernelGGL(k_price<MCF_RULE_DEVEX_BLOCK>, dim3(h->price_blocks), dim3(kPriceThreads), 0, s, h->view, lo, hi,
+                           use_block, h->d_cand);
+    else
+        hipLaunchKernelGGL(k_price<MCF_RULE_DANTZIG>, dim3(h->price_blocks), dim3(kPriceThreads), 0, s, h->view, lo, hi, 0,
+                           h->d_cand);
+}
+
+void launch_pivot_triplet(mcf_handle* h, hipStream_t s) {
+    const int32_t rule = h->opt.rule;
+    launch_price(h, s, rule, h->price_lo, h->price_hi, rule == MCF_RULE_DEVEX_BLOCK);
+    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, h->d_cand, h->price_blocks, rule,
+                       h->priced_per_pass);
+    hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
+}
+
+int build_graph(mcf_handle* h, int batch) {
+    if (h->graph_exec && h->graph_batch == batch) return MCF_OK;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream);
+    HIP_TRY(h, hipStreamEndCapture(h->stream, &h->graph));
+    HIP_TRY(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    h->graph_batch = batch;
+    return MCF_OK;
+}
+
+// One batch of pivots with every kernel bracketed by events (profile mode).
+int run_batch_profiled(mcf_handle* h, int batch) {
+    const size_t need = (size_t)batch * 4;
+    while (h->events.size() < need) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreate(&e));
+        h->events.push_back(e);
+    }
+    const int32_t rule = h->opt.rule;
+    for (int i = 0; i < batch; ++i) {
+        hipEvent_t* ev = &h->events[(size_t)i * 4];
+        HIP_TRY(h, hipEventRecord(ev[0], h->stream));
+        launch_price(h, h->stream, rule, h->price_lo, h->price_hi, rule == MCF_RULE_DEVEX_BLOCK);
+        HIP_TRY(h, hipEventRecord(ev[1], h->stream));
+        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, h->stream, h->view, h->d_cand, h->price_blocks, rule,
+                           h->priced_per_pass);
+        HIP_TRY(h, hipEventRecord(ev[2], h->stream));
+        hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, h->stream, h->view);
+        HIP_TRY(h, hipEventRecord(ev[3], h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < batch; ++i) {
+        hipEvent_t* ev = &h->events[(size_t)i * 4];
+        float a = 0, b = 0, c = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&c, ev[2], ev[3]);
+        h->stats.price_ms += a; h->stats.pivot_ms += b; h->stats.apply_ms += c;
+    }
+    h->stats.price_launches += batch; h->stats.pivot_launches += batch; h->stats.apply_launches += batch;
+    return MCF_OK;
+}
+
+int read_ctx(mcf_handle* h, hipStream_t s) {
+    HIP_TRY(h, hipMemcpyAsync(h->h_ctx, h->d_ctx, sizeof(McfCtx), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return MCF_OK;
+}
+
+void free_all(mcf_handle* h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
+    (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
+    (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_one);
+    if (h->h_ctx) (void)hipHostFree(h->h_ctx);
+    if (h->h_one) (void)hipHostFree(h->h_one);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int mcf_abi_version(void) { return MCF_ABI_VERSION; }
+
+int mcf_device_count(void) { return usable_devices(); }
+
+void mcf_default_options(mcf_options* opt) {
+    if (!opt) return;
+    std::memset(opt, 0, sizeof *opt);
+    opt->abi_version = MCF_ABI_VERSION;
+    opt->device = -1;
+    opt->rule = MCF_RULE_DANTZIG_FULL;
+    opt->batch_pivots = 64;
+    opt->use_graph = 1;
+}
+
+const char* mcf_last_error(mcf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, const int64_t* cost, const int64_t* cap,
+               const int64_t* supply, const mcf_options* opt_in, mcf_handle** out) {
+    if (!out) return MCF_E_BAD_ARG;
+    *out = nullptr;
+    mcf_options opt;
+    if (opt_in) opt = *opt_in; else mcf_default_options(&opt);
+    if (opt.abi_version != MCF_ABI_VERSION) { g_create_error = "mcf_options.abi_version mismatch"; return MCF_E_BAD_ARG; }
+    if (opt.rule != MCF_RULE_DANTZIG_FULL && opt.rule != MCF_RULE_DEVEX_BLOCK) { g_create_error = "unknown pricing rule"; return MCF_E_BAD_ARG; }
+    const int ndev = usable_devices();
+    if (ndev <= 0) { g_create_error = "no HIP device available (the engine has no CPU path)"; return MCF_E_NO_DEVICE; }
+    mcf_handle* h = new (std::nothrow) mcf_handle();
+    if (!h) return MCF_E_ALLOC;
+    int err = 0;
+    const std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, h->im, &err);
+    if (err) { g_create_error = msg; delete h; return err; }
+    h->opt = opt;
+    if (h->opt.batch_pivots <= 0) h->opt.batch_pivots = 64;
+    if (opt.device >= 0) {
+        if (opt.device >= ndev) { g_create_error = "device ordinal out of range"; delete h; return MCF_E_BAD_ARG; }
+        if (hipSetDevice(opt.device) != hipSuccess) { g_create_error = "hipSetDevice failed"; delete h; return MCF_E_HIP; }
+    }
+    if (hipGetDevice(&h->device) != hipSuccess) { g_create_error = "hipGetDevice failed"; delete h; return MCF_E_HIP; }
+    // shard
+    h->price_lo = opt.price_lo;
+    h->price_hi = (opt.price_lo == 0 && opt.price_hi == 0) ? m : opt.price_hi;
+    if (h->price_lo < 0 || h->price_hi > m || h->price_lo > h->price_hi || (h->price_lo & 3)) {
+        g_create_error = "bad price_lo/price_hi (0 <= lo <= hi <= m, lo multiple of 4)";
+        delete h;
+        return MCF_E_BAD_ARG;
+    }
+    const McfHostImage& im = h->im;
+    const int64_t shard_groups = ((h->price_hi - h->price_lo) + 1023) / 1024;  // 256 lanes x 4 arcs per block pass
+    int pb = opt.price_blocks > 0 ? opt.price_blocks : (int)(shard_groups < kMaxPriceBlocks ? shard_groups : kMaxPriceBlocks);
+    if (pb < 1) pb = 1;
+    h->price_blocks = pb;
+    {
+        const int64_t ab = ((int64_t)im.n_nodes + kApplyThreads - 1) / kApplyThreads;
+        h->apply_blocks = (int)(ab < kMaxApplyBlocks ? ab : kMaxApplyBlocks);
+    }
+
+    auto fail = [&](const char* what, hipError_t e) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+        free_all(h);
+        delete h;
+        return e == hipErrorOutOfMemory ? MCF_E_ALLOC : MCF_E_HIP;
+    };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    const size_t N = im.n_nodes;
+    if ((e = dalloc(&h->d_tail, im.m_pad)) != hipSuccess) return fail("hipMalloc tail", e);
+    if ((e = dalloc(&h->d_head, im.m_pad)) != hipSuccess) return fail("hipMalloc head", e);
+    if ((e = dalloc(&h->d_cost, im.m_pad)) != hipSuccess) return fail("hipMalloc cost", e);
+    if ((e = dalloc(&h->d_state, im.m_pad)) != hipSuccess) return fail("hipMalloc state", e);
+    if ((e = dalloc(&h->d_weight, im.m_pad)) != hipSuccess) return fail("hipMalloc weight", e);
+    if ((e = dalloc(&h->d_arcw, im.arcw.size())) != hipSuccess) return fail("hipMalloc arcw", e);
+    if ((e = dalloc(&h->d_pi, N)) != hipSuccess) return fail("hipMalloc pi", e);
+    if ((e = dalloc(&h->d_node, N)) != hipSuccess) return fail("hipMalloc node", e);
+    if ((e = dalloc(&h->d_order0, N)) != hipSuccess) return fail("hipMalloc order", e);
+    if ((e = dalloc(&h->d_order1, N)) != hipSuccess) return fail("hipMalloc order", e);
+    if ((e = dalloc(&h->d_path1, N)) != hipSuccess) return fail("hipMalloc path", e);
+    if ((e = dalloc(&h->d_path2, N)) != hipSuccess) return fail("hipMalloc path", e);
+    if ((e = dalloc(&h->d_seg, 2 * N + 2)) != hipSuccess) return fail("hipMalloc seg", e);
+    if ((e = dalloc(&h->d_ctx, 1)) != hipSuccess) return fail("hipMalloc ctx", e);
+    if ((e = dalloc(&h->d_cand, kMaxPriceBlocks)) != hipSuccess) return fail("hipMalloc cand", e);
+    if ((e = dalloc(&h->d_one, 1)) != hipSuccess) return fail("hipMalloc one", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_ctx), sizeof(McfCtx), hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_one), sizeof(McfCand), hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
+
+    McfView& v = h->view;
+    v.n_nodes = im.n_nodes;
+    v.m = im.m;
+    v.tail = h->d_tail; v.head = h->d_head; v.cost = h->d_cost; v.state = h->d_state;
+    v.weight = opt.rule == MCF_RULE_DEVEX_BLOCK ? h->d_weight : nullptr;
+    v.arcw = h->d_arcw; v.pi = h->d_pi; v.node = h->d_node;
+    v.order[0] = h->d_order0; v.order[1] = h->d_order1;
+    v.path1 = h->d_path1; v.path2 = h->d_path2; v.seg = h->d_seg; v.ctx = h->d_ctx;
+
+    const int rc = upload_image(h);
+    if (rc != MCF_OK) { g_create_error = h->err; free_all(h); delete h; return rc; }
+    *out = h;
+    return MCF_OK;
+}
+
+int mcf_reset(mcf_handle* h) {
+    if (!h) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return upload_image(h);
+}
+
+int mcf_set_max_pivots(mcf_handle* h, int64_t max_total_pivots) {
+    if (!h) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_ctl, dim3(1), dim3(1), 0, h->stream, h->d_ctx, max_total_pivots, 1);
+    HIP_TRY(h, hipGetLastError());
+    h->total_cap = max_total_pivots;
+    return MCF_OK;
+}
+
+int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user, int64_t cb_interval) {
+    if (!h) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t m = h->im.m, n = h->im.n;
+    if (max_pivots < 0) max_pivots = 20 * (m + n) > 100 ? 20 * (m + n) : 100;  // simplex.py:1470
+    int rc = read_ctx(h, h->stream);
+    if (rc) return rc;
+    const int64_t start = h->h_ctx->pivots;
+    const int64_t final_cap = start + max_pivots;
+    if (cb_interval <= 0) cb_interval = 100;
+    const int batch = h->opt.batch_pivots;
+    const bool graph = h->opt.use_graph && !h->opt.profile;
+    if (graph) { rc = build_graph(h, batch); if (rc) return rc; }
+    bool stop = false;
+    while (!stop) {
+        // inner cap: stop at the next progress point so the callback cadence is exact
+        int64_t cap = final_cap;
+        if (cb) {
+            const int64_t done = h->h_ctx->pivots - start;
+            const int64_t next_cb = start + (done / cb_interval + 1) * cb_interval;
+            if (next_cb < cap) cap = next_cb;
+        }
+        hipLaunchKernelGGL(k_ctl, dim3(1), dim3(1), 0, h->stream, h->d_ctx, cap, 1);
+        // pivot until the device reports something other than "still running"
+        for (;;) {
+            if (h->opt.profile) { rc = run_batch_profiled(h, batch); if (rc) return rc; }
+            else if (graph) HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
+            else for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream);
+            HIP_TRY(h, hipGetLastError());
+            rc = read_ctx(h, h->stream);
+            if (rc) return rc;
+            h->stats.batches += 1;
+            if (h->h_ctx->status != MCF_RUNNING) break;
+        }
+        const int32_t st = h->h_ctx->status;
+        if (st == MCF_PIVOT_LIMIT && h->h_ctx->pivots < final_cap) {
+            if (cb) {
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (cb(user, h->h_ctx->pivots, final_cap, el) != 0) stop = true;
+            }
+            continue;  // re-arm with the next cap
+        }
+        stop = true;
+    }
+    if (h->h_ctx->status == MCF_PIVOT_LIMIT) {
+        // simplex.py:1678-1699: at the budget, price once more to tell optimal from iteration_limit
+        int64_t arc = -1, key = 0; int32_t dir = 0;
+        rc = mcf_price_once(h, h->opt.rule == MCF_RULE_DEVEX_BLOCK ? MCF_RULE_DANTZIG_FULL : h->opt.rule, 0, m, &arc, &dir, &key);
+        if (rc) return rc;
+        if (arc < 0) {
+            h->h_ctx->status = MCF_OPTIMAL;
+            HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &h->h_ctx->status, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+    }
+    if (h->h_ctx->status == MCF_INTERNAL_ERROR) { h->err = "internal error: preorder permutation did not close"; return MCF_E_INTERNAL; }
+    h->stats.solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    h->solved_once = true;
+    return MCF_OK;
+}
+
+int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int64_t* flow, int64_t* potential,
+                   int8_t* in_tree, mcf_stats* stats) {
+    if (!h) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = read_ctx(h, h->stream);
+    if (rc) return rc;
+    const McfHostImage& im = h->im;
+    std::vector<McfArcW> arcw(im.arcw.size());
+    HIP_TRY(h, hipMemcpy(arcw.data(), h->d_arcw, arcw.size() * sizeof(McfArcW), hipMemcpyDeviceToHost));
+    McfHostResult r;
+    mcf_extract(im, arcw, h->h_ctx->status, r);
+    if (status) *status = r.status;
+    if (objective_hi_lo) {
+        objective_hi_lo[0] = (int64_t)(r.objective >> 64);
+        objective_hi_lo[1] = (int64_t)(uint64_t)r.objective;
+    }
+    if (flow) for (int64_t i = 0; i < im.m; ++i) flow[i] = arcw[i].flow;
+    if (potential) {
+        std::vector<int64_t> pi(im.n_nodes);
+        HIP_TRY(h, hipMemcpy(pi.data(), h->d_pi, pi.size() * 8, hipMemcpyDeviceToHost));
+        for (int32_t v = 0; v < im.n; ++v) potential[v] = pi[v] - pi[im.n];
+    }
+    if (in_tree) {
+        std::vector<int8_t> st(im.m_pad);
+        HIP_TRY(h, hipMemcpy(st.data(), h->d_state, st.size(), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < im.m; ++i) in_tree[i] = st[i] == 0;
+    }
+    if (stats) {
+        const McfCtx& c = *h->h_ctx;
+        h->stats.pivots = c.pivots; h->stats.degenerate = c.degenerate; h->stats.bound_flips = c.bound_flips;
+        h->stats.arcs_priced = c.arcs_priced; h->stats.nodes_moved = c.nodes_moved;
+        h->stats.subtree_nodes = c.subtree_nodes; h->stats.cycle_arcs = c.cycle_arcs;
+        h->stats.unbounded_arc = c.unbounded_arc;
+        h->stats.artificial_flow = r.artificial_flow;
+        h->stats.unbounded_rc = 0;
+        if (c.status == MCF_UNBOUNDED && c.unbounded_arc >= 0) {
+            std::vector<int64_t> pi(im.n_nodes);
+            HIP_TRY(h, hipMemcpy(pi.data(), h->d_pi, pi.size() * 8, hipMemcpyDeviceToHost));
+            const int64_t a = c.unbounded_arc;
+            const int64_t rcost = im.cost64[a] + pi[im.tail[a]] - pi[im.head[a]];
+            h->stats.unbounded_rc = rcost < 0 ? rcost : -rcost;
+        }
+        *stats = h->stats;
+    }
+    return MCF_OK;
+}
+
+int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int64_t* arc, int32_t* dir, int64_t* key) {
+    if (!h || !arc) return MCF_E_BAD_ARG;
+    if (rule != MCF_RULE_DANTZIG_FULL && rule != MCF_RULE_DEVEX_BLOCK) return MCF_E_BAD_ARG;
+    if (start < 0 || end > h->im.m || start > end) { h->err = "mcf_price_once: bad range"; return MCF_E_BAD_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    // price even when the solve has finished: temporarily view the control block as running
+    McfView v = h->view;
+    if (rule == MCF_RULE_DEVEX_BLOCK) v.weight = h->d_weight;
+    HIP_TRY(h, hipMemcpyAsync(h->h_ctx, h->d_ctx, sizeof(McfCtx), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int32_t saved = h->h_ctx->status;
+    int32_t running = MCF_RUNNING;
+    HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &running, 4, hipMemcpyHostToDevice, h->stream));
+    if (rule == MCF_RULE_DEVEX_BLOCK)
+        hipLaunchKernelGGL(k_price<MCF_RULE_DEVEX_BLOCK>, dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v, start, end, 0, h->d_cand);
+    else
+        hipLaunchKernelGGL(k_price<MCF_RULE_DANTZIG>, dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v, start, end, 0, h->d_cand);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, h->stream, h->d_cand, h->price_blocks, h->d_one);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &saved, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_one, h->d_one, sizeof(McfCand), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *arc = h->h_one->key > 0 ? h->h_one->arc : -1;
+    if (key) *key = h->h_one->key > 0 ? h->h_one->key : 0;
+    if (dir) {
+        *dir = 0;
+        if (*arc >= 0) {
+            int8_t st = 0;
+            HIP_TRY(h, hipMemcpy(&st, h->d_state + *arc, 1, hipMemcpyDeviceToHost));
+            *dir = st;
+        }
+    }
+    return MCF_OK;
+}
+
+int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev) {
+    if (!h || !cand_out_dev) return MCF_E_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int32_t rule = h->opt.rule;
+    launch_price(h, s, rule, h->price_lo, h->price_hi, rule == MCF_RULE_DEVEX_BLOCK);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, s, h->d_cand, h->price_blocks,
+                       reinterpret_cast<McfCand*>(cand_out_dev));
+    HIP_TRY(h, hipGetLastError());
+    return MCF_OK;
+}
+
+int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int32_t ncand) {
+    if (!h || !cands_dev || ncand < 1) return MCF_E_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // every rank accounts the arcs of ALL shards, so arcs_priced is the whole-job figure
+    const int64_t priced = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? h->h_ctx->block_size : h->im.m;
+    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, reinterpret_cast<const McfCand*>(cands_dev), ncand,
+                       h->opt.rule, priced);
+    hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
+    HIP_TRY(h, hipGetLastError());
+    return MCF_OK;
+}
+
+int mcf_poll(mcf_handle* h, void* stream, int32_t* status_or_running, int64_t* pivots) {
+    if (!h) return MCF_E_BAD_ARG;
+    const int rc = read_ctx(h, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    if (h->h_ctx->status == MCF_INTERNAL_ERROR) { h->err = "internal error: preorder permutation did not close"; return MCF_E_INTERNAL; }
+    if (status_or_running) {
+        const int32_t st = h->h_ctx->status;
+        // infeasibility (artificial flow left) is only resolved by mcf_get_result
+        *status_or_running = st == MCF_RUNNING ? -1 : st == MCF_OPTIMAL ? MCF_ST_OPTIMAL
+                             : st == MCF_UNBOUNDED ? MCF_ST_UNBOUNDED : MCF_ST_ITERATION_LIMIT;
+    }
+    if (pivots) *pivots = h->h_ctx->pivots;
+    return MCF_OK;
+}
+
+int mcf_time_pricing(mcf_handle* h, int32_t rule, int32_t reps, double* ms_per_launch) {
+    if (!h || !ms_per_launch || reps < 1) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    McfView v = h->view;
+    if (rule == MCF_RULE_DEVEX_BLOCK) v.weight = h->d_weight;
+    HIP_TRY(h, hipMemcpyAsync(h->h_ctx, h->d_ctx, sizeof(McfCtx), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int32_t saved = h->h_ctx->status;
+    int32_t running = MCF_RUNNING;
+    HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &running, 4, hipMemcpyHostToDevice, h->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    auto once = [&]() {
+        if (rule == MCF_RULE_DEVEX_BLOCK)
+            hipLaunchKernelGGL(k_price<MCF_RULE_DEVEX_BLOCK>, dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v, h->price_lo, h->price_hi, 1, h->d_cand);
+        else
+            hipLaunchKernelGGL(k_price<MCF_RULE_DANTZIG>, dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v, h->price_lo, h->price_hi, 0, h->d_cand);
+    };
+    once();  // warm
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) once();
+    HIP_TRY(h, hipEventRecord(e1, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &saved, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = (double)ms / reps;
+    return MCF_OK;
+}
+
+int mcf_time_copy(int32_t device, int64_t bytes, int32_t reps, double* ms_per_copy) {
+    if (!ms_per_copy || bytes < 16 || reps < 1) return MCF_E_BAD_ARG;
+    if (usable_devices() <= 0) return MCF_E_NO_DEVICE;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return MCF_E_HIP;
+    uint4 *a = nullptr, *b = nullptr;
+    const int64_t n16 = bytes / 16;
+    if (hipMalloc(reinterpret_cast<void**>(&a), n16 * 16) != hipSuccess) return MCF_E_ALLOC;
+    if (hipMalloc(reinterpret_cast<void**>(&b), n16 * 16) != hipSuccess) { (void)hipFree(a); return MCF_E_ALLOC; }
+    (void)hipMemset(a, 1, n16 * 16);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, nullptr, a, b, n16);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, nullptr, a, b, n16);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    *ms_per_copy = (double)ms / reps;
+    return hipGetLastError() == hipSuccess ? MCF_OK : MCF_E_HIP;
+}
+
+int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos, int32_t* order,
+                 int8_t* state, int64_t* potential_with_root) {
+    if (!h) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = read_ctx(h, h->stream);
+    if (rc) return rc;
+    const McfHostImage& im = h->im;
+    std::vector<McfNode> nodes(im.n_nodes);
+    HIP_TRY(h, hipMemcpy(nodes.data(), h->d_node, nodes.size() * sizeof(McfNode), hipMemcpyDeviceToHost));
+    for (int32_t v = 0; v < im.n_nodes; ++v) {
+        if (parent) parent[v] = nodes[v].parent;
+        if (pred_arc) pred_arc[v] = nodes[v].pred < 0 ? -1 : nodes[v].pred >> 1;
+        if (size) size[v] = nodes[v].size;
+        if (pos) pos[v] = nodes[v].pos;
+    }
+    if (order) {
+        const int cur = h->h_ctx->cur ^ (h->h_ctx->pending_flip ? 1 : 0);
+        HIP_TRY(h, hipMemcpy(order, cur ? h->d_order1 : h->d_order0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
+    }
+    if (state) HIP_TRY(h, hipMemcpy(state, h->d_state, (size_t)im.m, hipMemcpyDeviceToHost));
+    if (potential_with_root) HIP_TRY(h, hipMemcpy(potential_with_root, h->d_pi, (size_t)im.n_nodes * 8, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
+
+void mcf_destroy(mcf_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+"""ctypes binding of ``libmcf_hip.so`` (C ABI: ``include/mcf.h``).
+
+This is the only door between Python and the HIP engine.  There is no CPU
+fallback: if the shared library is missing, or no HIP device is usable,
+creating an engine raises ``EngineUnavailableError``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+from .exceptions import NetworkSolverError
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libmcf_hip.so"
+
+RULE_DANTZIG = 0
+RULE_DEVEX_BLOCK = 1
+STATUS_NAMES = {0: "optimal", 1: "infeasible", 2: "iteration_limit", 3: "unbounded"}
+CAP_INF = -1
+
+# every symbol include/mcf.h declares (tests check that the library exports each one)
+ABI_SYMBOLS = (
+    "mcf_default_options", "mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset",
+    "mcf_enqueue_price", "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing",
+    "mcf_time_copy", "mcf_get_tree", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
+)
+
+
+class EngineUnavailableError(NetworkSolverError):
+    """The HIP engine cannot run here (library not built, or no MI355X visible)."""
+
+
+class EngineError(NetworkSolverError):
+    """The HIP engine returned an error code."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"mcf error {code}: {message}")
+        self.code = code
+
+
+class McfOptions(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32), ("device", ctypes.c_int32), ("rule", ctypes.c_int32),
+        ("batch_pivots", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("profile", ctypes.c_int32),
+        ("block_size", ctypes.c_int64), ("price_lo", ctypes.c_int64), ("price_hi", ctypes.c_int64),
+        ("price_blocks", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
+class McfStats(ctypes.Structure):
+    _fields_ = [
+        ("pivots", ctypes.c_int64), ("degenerate", ctypes.c_int64), ("bound_flips", ctypes.c_int64),
+        ("arcs_priced", ctypes.c_int64), ("nodes_moved", ctypes.c_int64), ("subtree_nodes", ctypes.c_int64),
+        ("cycle_arcs", ctypes.c_int64), ("batches", ctypes.c_int64), ("unbounded_arc", ctypes.c_int64),
+        ("unbounded_rc", ctypes.c_int64), ("solve_seconds", ctypes.c_double), ("price_ms", ctypes.c_double),
+        ("pivot_ms", ctypes.c_double), ("apply_ms", ctypes.c_double), ("price_launches", ctypes.c_int64),
+        ("pivot_launches", ctypes.c_int64), ("apply_launches", ctypes.c_int64), ("price_bytes", ctypes.c_int64),
+        ("artificial_flow", ctypes.c_int64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+PROGRESS_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double)
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmcf_hip.so and declare the prototypes.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise EngineUnavailableError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The engine has no CPU fallback.")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    vp = ctypes.c_void_p
+    i32p, i64p, i8p = (ctypes.POINTER(t) for t in (ctypes.c_int32, ctypes.c_int64, ctypes.c_int8))
+    lib.mcf_abi_version.restype = ctypes.c_int
+    lib.mcf_device_count.restype = ctypes.c_int
+    lib.mcf_default_options.argtypes = [ctypes.POINTER(McfOptions)]
+    lib.mcf_default_options.restype = None
+    lib.mcf_create.argtypes = [ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p,
+                               ctypes.POINTER(McfOptions), ctypes.POINTER(vp)]
+    lib.mcf_solve.argtypes = [vp, ctypes.c_int64, PROGRESS_CB, vp, ctypes.c_int64]
+    lib.mcf_get_result.argtypes = [vp, i32p, i64p, i64p, i64p, i8p, ctypes.POINTER(McfStats)]
+    lib.mcf_price_once.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, i64p, i32p, i64p]
+    lib.mcf_reset.argtypes = [vp]
+    lib.mcf_enqueue_price.argtypes = [vp, vp, vp]
+    lib.mcf_enqueue_pivot.argtypes = [vp, vp, vp, ctypes.c_int32]
+    lib.mcf_poll.argtypes = [vp, vp, i32p, i64p]
+    lib.mcf_set_max_pivots.argtypes = [vp, ctypes.c_int64]
+    lib.mcf_time_pricing.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
+    lib.mcf_time_copy.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
+    lib.mcf_get_tree.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i8p, i64p]
+    lib.mcf_last_error.argtypes = [vp]
+    lib.mcf_last_error.restype = ctypes.c_char_p
+    lib.mcf_destroy.argtypes = [vp]
+    lib.mcf_destroy.restype = None
+    for name in ("mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_enqueue_price",
+                 "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing", "mcf_time_copy",
+                 "mcf_get_tree"):
+        getattr(lib, name).restype = ctypes.c_int
+    if lib.mcf_abi_version() != 1:
+        raise EngineUnavailableError("libmcf_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    return int(load_library().mcf_device_count())
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+@dataclass
+class EngineResult:
+    status: str
+    objective: int
+    flow: np.ndarray        # int64[m]
+    potential: np.ndarray   # int64[n]
+    in_tree: np.ndarray     # bool[m]
+    stats: dict
+
+
+class McfEngine:
+    """One device-resident min-cost-flow instance (integer data, 0-based node ids)."""
+
+    def __init__(self, n: int, tail, head, cost, cap, supply, rule: int = RULE_DANTZIG, block_size: int = 0,
+                 batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
+                 price_range: tuple[int, int] | None = None, price_blocks: int = 0):
+        self._h = None
+        lib = load_library()
+        if lib.mcf_device_count() <= 0:
+            raise EngineUnavailableError("no HIP device visible; the network-simplex engine has no CPU fallback")
+        self._lib = lib
+        self.n = int(n)
+        self.tail = np.ascontiguousarray(tail, dtype=np.int32)
+        self.head = np.ascontiguousarray(head, dtype=np.int32)
+        self.cost = np.ascontiguousarray(cost, dtype=np.int64)
+        self.cap = np.ascontiguousarray(cap, dtype=np.int64)
+        self.supply = np.ascontiguousarray(supply, dtype=np.int64)
+        self.m = int(self.tail.shape[0])
+        if not (self.head.shape[0] == self.cost.shape[0] == self.cap.shape[0] == self.m):
+            raise ValueError("arc arrays differ in length")
+        if self.supply.shape[0] != self.n:
+            raise ValueError("supply must have n entries")
+        opt = McfOptions()
+        lib.mcf_default_options(ctypes.byref(opt))
+        opt.device = device
+        opt.rule = rule
+        opt.block_size = int(block_size or 0)
+        opt.batch_pivots = int(batch_pivots)
+        opt.use_graph = 1 if use_graph else 0
+        opt.profile = 1 if profile else 0
+        opt.price_blocks = int(price_blocks)
+        if price_range is not None:
+            opt.price_lo, opt.price_hi = int(price_range[0]), int(price_range[1])
+        self.rule = rule
+        h = ctypes.c_void_p()
+        rc = lib.mcf_create(self.n, self.m, _p(self.tail, ctypes.c_int32), _p(self.head, ctypes.c_int32),
+                            _p(self.cost, ctypes.c_int64), _p(self.cap, ctypes.c_int64),
+                            _p(self.supply, ctypes.c_int64), ctypes.byref(opt), ctypes.byref(h))
+        if rc != 0:
+            msg = (lib.mcf_last_error(None) or b"").decode()
+            if rc == -2:
+                raise EngineUnavailableError(msg)
+            raise EngineError(rc, msg)
+        self._h = h
+
+    # -- helpers
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(rc, (self._lib.mcf_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h is not None:
+            self._lib.mcf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- solve path
+    def solve(self, max_pivots: int = -1, progress=None, progress_interval: int = 100) -> None:
+        """Pivot until optimal / unbounded / ``max_pivots`` more pivots.
+
+        ``progress(pivots, max_pivots, elapsed_seconds)`` is called every
+        ``progress_interval`` pivots; a truthy return value stops the solve.
+        """
+        if progress is not None:
+            def _cb(_user, pivots, cap, elapsed):
+                return 1 if progress(int(pivots), int(cap), float(elapsed)) else 0
+            cb = PROGRESS_CB(_cb)
+        else:
+            cb = PROGRESS_CB(0)
+        self._check(self._lib.mcf_solve(self._h, int(max_pivots), cb, None, int(progress_interval)))
+
+    def result(self) -> EngineResult:
+        status = ctypes.c_int32(0)
+        obj = np.zeros(2, dtype=np.int64)
+        flow = np.zeros(max(self.m, 1), dtype=np.int64)
+        pot = np.zeros(self.n, dtype=np.int64)
+        in_tree = np.zeros(max(self.m, 1), dtype=np.int8)
+        stats = McfStats()
+        self._check(self._lib.mcf_get_result(self._h, ctypes.byref(status), _p(obj, ctypes.c_int64),
+                                             _p(flow, ctypes.c_int64), _p(pot, ctypes.c_int64),
+                                             _p(in_tree, ctypes.c_int8), ctypes.byref(stats)))
+        objective = (int(obj[0]) << 64) + (int(obj[1]) & ((1 << 64) - 1))
+        return EngineResult(STATUS_NAMES[status.value], objective, flow[: self.m], pot,
+                            in_tree[: self.m].astype(bool), stats.as_dict())
+
+    def stats(self) -> dict:
+        stats = McfStats()
+        status = ctypes.c_int32(0)
+        self._check(self._lib.mcf_get_result(self._h, ctypes.byref(status), None, None, None, None,
+                                             ctypes.byref(stats)))
+        d = stats.as_dict()
+        d["status"] = STATUS_NAMES[status.value]
+        return d
+
+    def reset(self) -> None:
+        self._check(self._lib.mcf_reset(self._h))
+
+    def price_once(self, rule: int | None = None, start: int = 0, end: int | None = None):
+        """One pricing pass. Returns (arc, dir, key) or None when no arc is eligible."""
+        arc, key, d = ctypes.c_int64(-1), ctypes.c_int64(0), ctypes.c_int32(0)
+        self._check(self._lib.mcf_price_once(self._h, self.rule if rule is None else rule, int(start),
+                                             self.m if end is None else int(end), ctypes.byref(arc),
+                                             ctypes.byref(d), ctypes.byref(key)))
+        return None if arc.value < 0 else (int(arc.value), int(d.value), int(key.value))
+
+    def tree(self) -> dict:
+        N = self.n + 1
+        parent, pred, size, pos, order = (np.zeros(N, dtype=np.int32) for _ in range(5))
+        state = np.zeros(max(self.m, 1), dtype=np.int8)
+        pi = np.zeros(N, dtype=np.int64)
+        i32 = ctypes.c_int32
+        self._check(self._lib.mcf_get_tree(self._h, _p(parent, i32), _p(pred, i32), _p(size, i32), _p(pos, i32),
+                                           _p(order, i32), _p(state, ctypes.c_int8), _p(pi, ctypes.c_int64)))
+        return {"parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order,
+                "state": state[: self.m], "pi": pi}
+
+    # -- measurement
+    def time_pricing(self, reps: int = 20, rule: int | None = None) -> float:
+        ms = ctypes.c_double(0.0)
+        self._check(self._lib.mcf_time_pricing(self._h, self.rule if rule is None else rule, int(reps), ctypes.byref(ms)))
+        return float(ms.value)
+
+    # -- multi-GPU (arc-sharded) building blocks
+    def enqueue_price(self, stream: int, cand_out_ptr: int) -> None:
+        self._check(self._lib.mcf_enqueue_price(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(cand_out_ptr)))
+
+    def enqueue_pivot(self, stream: int, cands_ptr: int, ncand: int) -> None:
+        self._check(self._lib.mcf_enqueue_pivot(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(cands_ptr), int(ncand)))
+
+    def poll(self, stream: int = 0):
+        st, pv = ctypes.c_int32(0), ctypes.c_int64(0)
+        self._check(self._lib.mcf_poll(self._h, ctypes.c_void_p(stream), ctypes.byref(st), ctypes.byref(pv)))
+        return (None if st.value < 0 else int(st.value)), int(pv.value)
+
+    def set_max_pivots(self, total: int) -> None:
+        self._check(self._lib.mcf_set_max_pivots(self._h, int(total)))
+
+
+def time_copy(nbytes: int, reps: int = 10, device: int = -1) -> float:
+    """Milliseconds per device-to-device copy of ``nbytes`` (measured HBM copy ceiling)."""
+    lib = load_library()
+    ms = ctypes.c_double(0.0)
+    rc = lib.mcf_time_copy(device, int(nbytes), int(reps), ctypes.byref(ms))
+    if rc == -2:
+        raise EngineUnavailableError("no HIP device visible")
+    if rc != 0:
+        raise EngineError(rc, "mcf_time_copy failed")
+    return float(ms.value)

@@ -1,0 +1,226 @@
+"""``NetworkSimplex`` facade: the reference's solver object, backed by the HIP engine.
+
+Constructor / ``solve`` signature and the shape of everything that comes back
+follow /root/reference/src/network_solver/simplex.py (``NetworkSimplex`` :62,
+``__init__`` :99, ``solve`` :1446-1452).  What happens in between is different:
+
+* the problem is flattened once into integer structure-of-arrays form
+  (``flatten_problem``: the reference's node/arc ordering :149,:395, lower-bound
+  shift :403-428, undirected expansion data.py:162-223, plus a decimal scaling
+  step because the engine is integer);
+* the pivot loop (:1109-1160, :1176-1425) runs on the MI355X through
+  ``engine.McfEngine`` -- nothing in this module prices an arc or walks a tree;
+* results are mapped back with the reference's post-processing (:1703-1765):
+  flows summed per ``(tail, head)`` key, ``|f| <= tolerance`` dropped,
+  ``round(., 12)``, objective over the original costs.
+
+There is no CPU fallback here: without the HIP library or a GPU,
+``NetworkSimplex(...)`` raises ``EngineUnavailableError``.
+"""
+
+from __future__ import annotations
+
+import logging
+import math
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import engine as _engine
+from .data import Basis, FlowResult, NetworkProblem, ProgressCallback, ProgressInfo, SolverOptions
+from .exceptions import InvalidProblemError, SolverConfigurationError, UnboundedProblemError
+
+_MAX_DECIMALS = 9
+
+
+@dataclass
+class FlatProblem:
+    """Integer SoA image of a NetworkProblem plus what is needed to map results back."""
+
+    node_ids: list[str]            # index -> id, string-sorted like the reference
+    keys: list[tuple[str, str]]    # per arc (tail id, head id), reference arc order
+    tail: np.ndarray               # int32[m]
+    head: np.ndarray               # int32[m]
+    cost: np.ndarray               # int64[m]   cost * cost_scale
+    cap: np.ndarray                # int64[m]   (capacity - lower) * flow_scale, -1 = unlimited
+    supply: np.ndarray             # int64[n]   (supply shifted by lower bounds) * flow_scale
+    lower: np.ndarray              # float64[m] original lower bounds (the shift)
+    orig_cost: np.ndarray          # float64[m]
+    flow_scale: int
+    cost_scale: int
+
+
+def _decimal_scale(values: np.ndarray, what: str) -> int:
+    """Smallest power of ten that makes every value an integer (exactly, up to 1e-9 relative)."""
+    if values.size == 0:
+        return 1
+    if not np.all(np.isfinite(values)):
+        raise InvalidProblemError(f"{what} must be finite numbers")
+    for k in range(_MAX_DECIMALS + 1):
+        scaled = values * (10.0 ** k)
+        if np.all(np.abs(scaled - np.round(scaled)) <= 1e-9 * np.maximum(1.0, np.abs(scaled))):
+            return 10 ** k
+    raise SolverConfigurationError(
+        f"{what} need more than {_MAX_DECIMALS} decimal digits; the integer MI355X engine cannot "
+        f"represent them exactly")
+
+
+def flatten_problem(problem: NetworkProblem) -> FlatProblem:
+    """NetworkProblem -> integer SoA, in the reference's internal order."""
+    node_ids = sorted(problem.nodes.keys())                       # simplex.py:149
+    index = {nid: i for i, nid in enumerate(node_ids)}
+    arcs = sorted(problem.undirected_expansion(), key=lambda a: (a.tail, a.head))  # simplex.py:394-395
+    m = len(arcs)
+    tol = problem.tolerance
+    supply = np.array([problem.nodes[nid].supply for nid in node_ids], dtype=np.float64)
+    if abs(float(supply.sum())) > tol:                            # simplex.py:381-390
+        raise InvalidProblemError(
+            f"Supplies do not balance after lower-bound adjustment: total supply {supply.sum():.6f} "
+            f"exceeds tolerance {tol}.")
+    tail = np.fromiter((index[a.tail] for a in arcs), dtype=np.int32, count=m)
+    head = np.fromiter((index[a.head] for a in arcs), dtype=np.int32, count=m)
+    cost = np.fromiter((a.cost for a in arcs), dtype=np.float64, count=m)
+    lower = np.fromiter((a.lower for a in arcs), dtype=np.float64, count=m)
+    upper = np.empty(m, dtype=np.float64)
+    for i, a in enumerate(arcs):                                  # simplex.py:399-412
+        if a.capacity is None:
+            upper[i] = math.inf
+        else:
+            u = float(a.capacity) - a.lower
+            if u < -tol:
+                raise InvalidProblemError(
+                    f"Arc capacity ({a.capacity}) is less than lower bound ({a.lower}) for arc "
+                    f"{a.tail} -> {a.head}. Capacity must be >= lower bound.")
+            upper[i] = max(0.0, u)
+    np.subtract.at(supply, tail, lower)                           # simplex.py:413-415
+    np.add.at(supply, head, lower)
+    finite = np.isfinite(upper)
+    flow_scale = _decimal_scale(np.concatenate((supply, upper[finite], lower)), "supplies / capacities / lower bounds")
+    cost_scale = _decimal_scale(cost, "costs")
+    cap_i = np.full(m, -1, dtype=np.int64)
+    cap_i[finite] = np.round(upper[finite] * flow_scale).astype(np.int64)
+    supply_i = np.round(supply * flow_scale).astype(np.int64)
+    residual = int(supply_i.sum())
+    if residual != 0:
+        # the reference tolerates |sum| <= tolerance; put the sub-tolerance remainder on the largest node
+        supply_i[int(np.argmax(np.abs(supply_i)))] -= residual
+    cost_i = np.round(cost * cost_scale).astype(np.int64)
+    if m and (np.abs(cost_i).max() >= 2 ** 31 or (cap_i.max() >= 2 ** 60)):
+        raise SolverConfigurationError("scaled costs must fit int32 and scaled capacities int60")
+    return FlatProblem(node_ids, [(a.tail, a.head) for a in arcs], tail, head, cost_i, cap_i, supply_i, lower,
+                       cost, flow_scale, cost_scale)
+
+
+class NetworkSimplex:
+    """Network simplex solver for minimum-cost flow, pivoting on an MI355X.
+
+    Same construction and ``solve`` contract as the reference class
+    (simplex.py:62-265, :1446-1765).  ``SolverOptions.pricing_strategy``:
+    ``"dantzig"`` selects the full-scan pricing kernel; ``"devex"``, ``"candidate_list"`` and
+    ``"adaptive"`` select the block-search Devex kernel (the reference's candidate-list /
+    adaptive rules are host-side heuristics around the same reduced-cost sweep; the optimum
+    they reach is the same).
+    """
+
+    ROOT_NODE = "__network_simplex_root__"
+
+    def __init__(self, problem: NetworkProblem, options: SolverOptions | None = None, *, device: int = -1,
+                 batch_pivots: int = 64, use_graph: bool = True):
+        self.options = options if options is not None else SolverOptions()
+        self.logger = logging.getLogger(__name__)
+        self.problem = problem
+        self.tolerance = self.options.tolerance
+        self.flat = flatten_problem(problem)
+        self.node_ids = [self.ROOT_NODE] + self.flat.node_ids
+        self.actual_arc_count = len(self.flat.keys)
+        self.degenerate_pivots = 0
+        strategy = self._select_pricing_strategy()
+        self.pricing_rule = _engine.RULE_DANTZIG if strategy == "dantzig" else _engine.RULE_DEVEX_BLOCK
+        bs = self.options.block_size
+        block_size = 0 if bs is None or isinstance(bs, str) else int(bs)
+        self.engine = _engine.McfEngine(
+            len(self.flat.node_ids), self.flat.tail, self.flat.head, self.flat.cost, self.flat.cap,
+            self.flat.supply, rule=self.pricing_rule, block_size=block_size, batch_pivots=batch_pivots,
+            use_graph=use_graph, device=device)
+        self.stats: dict = {}
+
+    # simplex.py:314-374: the reference's grid-on-torus heuristic switches to Dantzig unless the
+    # caller pinned a strategy
+    def _select_pricing_strategy(self) -> str:
+        if self.options.explicit_pricing_strategy:
+            return self.options.pricing_strategy
+        nodes = self.problem.nodes
+        n = len(nodes)
+        m = self.actual_arc_count
+        if n == 0:
+            return self.options.pricing_strategy
+        non_transship = sum(1 for nd in nodes.values() if abs(nd.supply) > self.tolerance)
+        if (non_transship <= 4 and (n - non_transship) / n > 0.98 and (2 * m) / n >= 8 and 6 <= m / n <= 12):
+            self.logger.info("Auto-detected grid-on-torus structure, switching to Dantzig pricing")
+            return "dantzig"
+        return self.options.pricing_strategy
+
+    def _objective_estimate(self, flow: np.ndarray) -> float:
+        f = self.flat
+        return float(np.dot(flow / f.flow_scale + f.lower, f.orig_cost))
+
+    def solve(self, max_iterations: int | None = None, progress_callback: ProgressCallback | None = None,
+              progress_interval: int = 100, warm_start_basis: Basis | None = None) -> FlowResult:
+        """Solve; returns a FlowResult, raises UnboundedProblemError (simplex.py:1446-1765)."""
+        f = self.flat
+        n, m = len(f.node_ids), self.actual_arc_count
+        if max_iterations is None:
+            max_iterations = self.options.max_iterations
+        if max_iterations is None:
+            max_iterations = max(100, 20 * (m + n))               # simplex.py:1470 (len(arcs) incl. artificial)
+        if warm_start_basis is not None:
+            self.logger.warning("warm_start_basis is not applied by the MI355X engine yet; cold start")
+        start = time.time()
+
+        progress = None
+        if progress_callback is not None:
+            def progress(pivots: int, cap: int, elapsed: float):
+                res = self.engine.result()
+                phase = 1 if res.stats["artificial_flow"] > 0 else 2
+                progress_callback(ProgressInfo(iteration=pivots, max_iterations=max_iterations, phase=phase,
+                                               phase_iterations=pivots,
+                                               objective_estimate=self._objective_estimate(res.flow),
+                                               elapsed_time=time.time() - start))
+                return False
+
+        self.engine.solve(max_iterations, progress, progress_interval)
+        res = self.engine.result()
+        self.stats = res.stats
+        iterations = int(res.stats["pivots"])
+        self.degenerate_pivots = int(res.stats["degenerate"])
+
+        if res.status == "unbounded":                             # simplex.py:1231-1246
+            arc = int(res.stats["unbounded_arc"])
+            raise UnboundedProblemError(
+                "Unbounded problem detected: entering arc can increase indefinitely without hitting any "
+                "capacity constraint. This indicates a negative-cost cycle with infinite capacity.",
+                entering_arc=f.keys[arc] if 0 <= arc < m else None,
+                reduced_cost=res.stats["unbounded_rc"] / f.cost_scale)
+        if res.status == "infeasible" or (res.status == "iteration_limit" and res.stats["artificial_flow"] > 0):
+            # simplex.py:1600-1624: no feasible flow (or none found within the budget)
+            return FlowResult(objective=0.0, flows={}, status=res.status, iterations=iterations, duals={})
+
+        flow_value = res.flow.astype(np.float64) / f.flow_scale + f.lower   # flow + shift
+        flows: dict[tuple[str, str], float] = {}
+        objective = 0.0
+        for i, key in enumerate(f.keys):                          # simplex.py:1703-1714
+            fv = float(flow_value[i])
+            flows[key] = flows.get(key, 0.0) + fv
+            objective += fv * float(f.orig_cost[i])
+        for key, value in list(flows.items()):                    # simplex.py:1716-1721
+            if abs(value) <= self.tolerance:
+                flows.pop(key)
+            else:
+                flows[key] = float(round(value, 12))
+        duals = {nid: float(round(int(res.potential[i]) / f.cost_scale, 12)) for i, nid in enumerate(f.node_ids)}
+        basis = Basis(                                            # simplex.py:1029-1039
+            tree_arcs={f.keys[i] for i in np.nonzero(res.in_tree)[0]},
+            arc_flows={f.keys[i]: float(res.flow[i]) / f.flow_scale for i in np.nonzero(res.in_tree)[0]})
+        return FlowResult(objective=float(round(objective, 12)), flows=flows, status=res.status,
+                          iterations=iterations, duals=duals, basis=basis)
