@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- pivots/sec + arcs-priced/sec of the MI355X network-simplex engine.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A *step* is one pivot: one pass of the hot path (pricing sweep -> ratio test / flow update
+-> tree + potential update) over the device-resident instance.  W untimed pivots, then
+EXACTLY K timed pivots between barrier + device synchronisation on both sides; rank 0 prints
+ONE JSON line.  Inputs are resident in HBM before the timed region starts.
+
+Workload at N=1 (default): BASELINE.json configs[1] -- "netgen_8_08a, 1xMI355X, full-scan
+Dantzig pricing kernel" -- as a seeded synthetic stand-in (the LEMON file is not obtainable
+offline).  That instance is 27 KB per sweep, i.e. launch-latency-bound by construction, so
+the same line also carries ``hbm_point``: the same measurement on BASELINE.json configs[4]'s
+shape (1M nodes / 16M arcs), the one configuration whose pricing sweep is HBM-bound and for
+which BASELINE.json asks for the roofline fraction.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Every rank holds the
+replicated instance, prices its own contiguous arc shard, and one 16-byte all-gather per
+pivot picks the entering arc.  Weak scaling: arcs per GPU are fixed,
+``value`` is the whole-job arcs-priced/sec.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (family builder args) -- per-GPU shape; at N GPUs the instance has N x the arcs and nodes
+    "netgen_8_08a": ("netgen", 256, 2048),
+    "netgen_8_14a": ("netgen", 16384, 131072),
+    "netgen_8_16a": ("netgen", 65536, 524288),
+    "netgen_8_20a": ("netgen", 1 << 20, 8 << 20),
+    "netgen_1m_16m": ("netgen", 1 << 20, 16 << 20),
+}
+
+
+def make_instance(workload: str, scale: int = 1):
+    from network_flow_solver_amd import generators
+
+    fam, n, m = WORKLOADS[workload]
+    return generators.netgen_style(n * scale, m * scale, seed=1, name=f"{workload}(synthetic,x{scale})")
+
+
+def run_pivots(eng, count: int):
+    """Exactly `count` more pivots; restarts from the start basis when the optimum is reached."""
+    done = 0
+    restarts = 0
+    while done < count:
+        before = eng.stats()["pivots"]
+        eng.solve(max_pivots=count - done)
+        st = eng.stats()
+        done += st["pivots"] - before
+        if st["status"] != "iteration_limit" and done < count:
+            eng.reset()
+            restarts += 1
+    return restarts
+
+
+def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pass: bool = True) -> dict:
+    import torch
+
+    from network_flow_solver_amd import engine
+
+    inst = make_instance(workload)
+    eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, device=0)
+    run_pivots(eng, warmup)
+    s0 = eng.stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    restarts = run_pivots(eng, steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = eng.stats()
+    pivots = s1["pivots"] - s0["pivots"] if restarts == 0 else steps
+    arcs = s1["arcs_priced"] - s0["arcs_priced"] if restarts == 0 else steps * inst.m
+    out = {
+        "workload": f"{inst.name}: {inst.n} nodes / {inst.m} arcs", "n": inst.n, "m": inst.m,
+        "pivots": int(pivots), "seconds": dt, "pivots_per_sec": pivots / dt, "arcs_priced_per_sec": arcs / dt,
+        "ms_per_step": 1e3 * dt / max(pivots, 1), "restarts": restarts,
+    }
+    # dominant-kernel timing: HIP events on the engine's stream around every kernel of the same
+    # K pivots (second pass from the same start state, deterministic -> same pivots)
+    if profile_pass:
+        eng.close()
+        eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, device=0,
+                               profile=True)
+        run_pivots(eng, warmup)
+        p0 = eng.stats()
+        run_pivots(eng, steps)
+        p1 = eng.stats()
+        launches = max(p1["price_launches"] - p0["price_launches"], 1)
+        price_ms = (p1["price_ms"] - p0["price_ms"]) / launches
+        pivot_ms = (p1["pivot_ms"] - p0["pivot_ms"]) / launches
+        apply_ms = (p1["apply_ms"] - p0["apply_ms"]) / launches
+        bytes_per_launch = p1["price_bytes"]            # 13 B/arc + 8 B/node
+        sweep_ms = eng.time_pricing(reps=50)            # back-to-back launches, no events in between
+        achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9
+        out["kernel_ms"] = {"price": price_ms, "pivot": pivot_ms, "apply": apply_ms, "price_back_to_back": sweep_ms}
+        out["roofline"] = {
+            "kernel": "k_price<dantzig>" if rule == 0 else "k_price<devex_block>", "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None, "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": sweep_ms,
+            "ms_per_launch_in_pivot_loop": price_ms,
+        }
+    eng.close()
+    return out
+
+
+def cpu_baseline(workload: str, budget_seconds: float = 12.0) -> dict:
+    """The oracle -- a single-threaded C restatement of the reference's algorithm -- on the same
+    workload, bounded to roughly `budget_seconds` of CPU work."""
+    import oracle
+
+    inst = make_instance(workload)
+    if inst.m <= 1 << 17:
+        t0 = time.perf_counter()
+        pivots = arcs = 0
+        solves = 0
+        while time.perf_counter() - t0 < budget_seconds:
+            r = oracle.solve_soa(inst, "dantzig", reference_order=False)
+            pivots += r["iterations"]
+            arcs += r["arcs_priced"]
+            solves += 1
+        dt = time.perf_counter() - t0
+        sample = f"{solves} complete Dantzig solves of {inst.name}"
+    else:
+        budget = 6
+        r = oracle.solve_soa(inst, "dantzig", reference_order=False, pivot_budget=budget)
+        per = r["seconds"] / max(r["iterations"], 1)
+        budget = int(max(6, min(400, budget_seconds / max(per, 1e-9))))
+        r = oracle.solve_soa(inst, "dantzig", reference_order=False, pivot_budget=budget)
+        pivots, arcs, dt = r["iterations"], r["arcs_priced"], r["seconds"]
+        sample = f"first {pivots} Dantzig pivots of {inst.name}"
+    return {"value": pivots / dt, "unit": "pivots/s", "arcs_priced_per_sec": arcs / dt, "cores": 1, "kind": "port",
+            "sample": sample, "host_cores_available": os.cpu_count(),
+            "note": "oracle/ref_simplex.c: the reference's float64 two-phase algorithm (per-pivot BFS rebuild + "
+                    "full Dantzig scan) restated in C, 1 thread; the pure-Python reference itself cannot travel"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--rule", default="dantzig", choices=["dantzig", "devex"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-point", action="store_true")
+    args = ap.parse_args()
+    rule = 0 if args.rule == "dantzig" else 1
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from network_flow_solver_amd import distributed
+
+        distributed.bench_main(args, WORKLOADS, HBM_PEAK_GBPS)
+        return
+
+    import __graft_entry__ as ge
+
+    ge.build_hip()
+    workload = args.workload or "netgen_8_08a"
+    head = measure_single(workload, args.steps, args.warmup, rule)
+    line = {
+        "metric": "pivots/sec + arcs-priced/sec (value = arcs-priced/sec; pivots_per_sec alongside) on netgen_8-style DIMACS",
+        "value": head["arcs_priced_per_sec"], "unit": "arcs/s", "pivots_per_sec": head["pivots_per_sec"],
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": head["workload"], "pricing": "full-scan Dantzig" if rule == 0 else "block-search Devex",
+                   "step": "one pivot (price + ratio test + tree/potential update)", "parallelism": "1 GPU",
+                   "restarts_in_timed_region": head["restarts"]},
+        "roofline": head.get("roofline"), "kernel_ms": head.get("kernel_ms"),
+        "reference_published": {"pivots_per_sec": 52, "instance": "netgen_8_08a (real file)", "hardware": "unstated CPU",
+                                "source": "benchmarks/results/after-iteration-fix.json:89-98"},
+    }
+    if not args.no_hbm_point and workload == "netgen_8_08a":
+        big = measure_single("netgen_1m_16m", min(args.steps, 200), min(args.warmup, 20), rule)
+        line["hbm_point"] = {
+            "workload": big["workload"], "value": big["arcs_priced_per_sec"], "unit": "arcs/s",
+            "pivots_per_sec": big["pivots_per_sec"], "ms_per_step": big["ms_per_step"], "steps": big["pivots"],
+            "roofline": big.get("roofline"), "kernel_ms": big.get("kernel_ms"),
+        }
+        try:
+            from network_flow_solver_amd import engine
+
+            ms = engine.time_copy(1 << 30, reps=10)
+            line["hbm_point"]["measured_copy_GBps"] = 2 * (1 << 30) / (ms * 1e-3) / 1e9  # read + write
+        except Exception as exc:  # measurement aid only
+            line["hbm_point"]["measured_copy_GBps"] = None
+            line["hbm_point"]["copy_error"] = str(exc)
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(workload)
+        if "hbm_point" in line:
+            line["hbm_point"]["cpu_baseline"] = cpu_baseline("netgen_1m_16m", budget_seconds=15.0)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -99,7 +99,8 @@ typedef struct mcf_stats {
     int64_t pivot_launches;
     int64_t apply_launches;
     int64_t price_bytes;      /* algorithmic bytes of one pricing launch: 13 B/arc + 8 B/node (17 for Devex) */
-    int64_t artificial_flow;  /* flow still on artificial arcs (> 0 at optimality = infeasible, simplex.py:1573-1624) */
+    int64_t artificial_flow;  /* flow still on artificial arcs (> 0 at optimality = infeasible, simplex.py:1573-1624);
+                                 -1 when mcf_get_result was asked for neither status, objective nor flow */
 } mcf_stats;
 
 /* Called from mcf_solve every cb_interval pivots (simplex.py:1143-1154).

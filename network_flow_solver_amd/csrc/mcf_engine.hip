@@ -540,10 +540,16 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
     int rc = read_ctx(h, h->stream);
     if (rc) return rc;
     const McfHostImage& im = h->im;
-    std::vector<McfArcW> arcw(im.arcw.size());
-    HIP_TRY(h, hipMemcpy(arcw.data(), h->d_arcw, arcw.size() * sizeof(McfArcW), hipMemcpyDeviceToHost));
+    // the flow copy (16 B per arc) is only made when something derived from it is asked for
+    const bool need_arcw = status || objective_hi_lo || flow;
+    std::vector<McfArcW> arcw;
     McfHostResult r;
-    mcf_extract(im, arcw, h->h_ctx->status, r);
+    r.artificial_flow = -1;
+    if (need_arcw) {
+        arcw.resize(im.arcw.size());
+        HIP_TRY(h, hipMemcpy(arcw.data(), h->d_arcw, arcw.size() * sizeof(McfArcW), hipMemcpyDeviceToHost));
+        mcf_extract(im, arcw, h->h_ctx->status, r);
+    }
     if (status) *status = r.status;
     if (objective_hi_lo) {
         objective_hi_lo[0] = (int64_t)(r.objective >> 64);

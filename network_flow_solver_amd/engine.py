@@ -231,12 +231,13 @@ class McfEngine:
                             in_tree[: self.m].astype(bool), stats.as_dict())
 
     def stats(self) -> dict:
+        """Counters + coarse status without copying the flows back (status is one of
+        running / optimal / iteration_limit / unbounded; infeasibility needs ``result()``)."""
         stats = McfStats()
-        status = ctypes.c_int32(0)
-        self._check(self._lib.mcf_get_result(self._h, ctypes.byref(status), None, None, None, None,
-                                             ctypes.byref(stats)))
+        self._check(self._lib.mcf_get_result(self._h, None, None, None, None, None, ctypes.byref(stats)))
         d = stats.as_dict()
-        d["status"] = STATUS_NAMES[status.value]
+        st, _ = self.poll()
+        d["status"] = "running" if st is None else STATUS_NAMES[st]
         return d
 
     def reset(self) -> None:

