@@ -43,6 +43,7 @@ WORKLOADS = {
     "netgen_8_08a": ("netgen", 256, 2048),
     "netgen_8_14a": ("netgen", 16384, 131072),
     "netgen_8_16a": ("netgen", 65536, 524288),
+    "netgen_8_18a": ("netgen", 262144, 2097152),
     "netgen_8_20a": ("netgen", 1 << 20, 8 << 20),
     "netgen_1m_16m": ("netgen", 1 << 20, 16 << 20),
 }

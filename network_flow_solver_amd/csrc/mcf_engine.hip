@@ -467,6 +467,8 @@ int mcf_set_max_pivots(mcf_handle* h, int64_t max_total_pivots) {
     HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(k_ctl, dim3(1), dim3(1), 0, h->stream, h->d_ctx, max_total_pivots, 1);
     HIP_TRY(h, hipGetLastError());
+    // the caller enqueues the pivots on a stream of its own: make the new cap visible first
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total_cap = max_total_pivots;
     return MCF_OK;
 }

@@ -332,3 +332,59 @@ def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int 
         "seconds": stats[9] / 1e9, "parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order,
         "trace": tr[:trace] if trace else None,
     }
+
+
+class EmulStepper:
+    """Step-wise handle on the CPU emulation (one replica): price a shard, apply a pivot.
+    Mirrors how the HIP engine is driven per pivot in the arc-sharded multi-GPU loop."""
+
+    def __init__(self, n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0):
+        lib = _load_emul()
+        i32p, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+        lib.emul_create.restype = ctypes.c_void_p
+        lib.emul_create.argtypes = [ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, ctypes.c_int32, ctypes.c_int64]
+        lib.emul_price.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, i64p]
+        lib.emul_price.restype = None
+        lib.emul_pivot.argtypes = [ctypes.c_void_p, i64p, ctypes.c_int32]
+        lib.emul_pivot.restype = None
+        lib.emul_set_max_pivots.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        lib.emul_set_max_pivots.restype = None
+        lib.emul_poll.argtypes = [ctypes.c_void_p, i32p, i64p, i64p, i64p]
+        lib.emul_poll.restype = None
+        lib.emul_destroy.argtypes = [ctypes.c_void_p]
+        lib.emul_destroy.restype = None
+        self._lib = lib
+        self.m = int(len(tail))
+        self._keep = [np.ascontiguousarray(tail, np.int32), np.ascontiguousarray(head, np.int32),
+                      np.ascontiguousarray(cost, np.int64), np.ascontiguousarray(cap, np.int64),
+                      np.ascontiguousarray(supply, np.int64)]
+        t, h, c, cp, s = self._keep
+        self._h = lib.emul_create(int(n), self.m, _ptr(t, ctypes.c_int32), _ptr(h, ctypes.c_int32),
+                                  _ptr(c, ctypes.c_int64), _ptr(cp, ctypes.c_int64), _ptr(s, ctypes.c_int64),
+                                  int(rule), int(block_size))
+        if not self._h:
+            raise RuntimeError("emul_create failed")
+
+    def price(self, lo: int, hi: int, out: np.ndarray) -> None:
+        """out: int64[2] <- (key, arc) of the best candidate in [lo, hi)."""
+        self._lib.emul_price(self._h, int(lo), int(hi), _ptr(out, ctypes.c_int64))
+
+    def pivot(self, cands: np.ndarray, ncand: int) -> None:
+        self._lib.emul_pivot(self._h, _ptr(cands, ctypes.c_int64), int(ncand))
+
+    def set_max_pivots(self, cap: int) -> None:
+        self._lib.emul_set_max_pivots(self._h, int(cap))
+
+    def poll(self, want_flow: bool = False):
+        st, pv = ctypes.c_int32(0), ctypes.c_int64(0)
+        obj = np.zeros(2, np.int64)
+        flow = np.zeros(max(self.m, 1), np.int64) if want_flow else None
+        self._lib.emul_poll(self._h, ctypes.byref(st), ctypes.byref(pv), _ptr(obj, ctypes.c_int64),
+                            _ptr(flow, ctypes.c_int64) if want_flow else None)
+        objective = (int(obj[0]) << 64) + (int(obj[1]) & ((1 << 64) - 1))
+        return (None if st.value < 0 else int(st.value)), int(pv.value), objective, (flow[: self.m] if want_flow else None)
+
+    def close(self):
+        if self._h:
+            self._lib.emul_destroy(self._h)
+            self._h = None

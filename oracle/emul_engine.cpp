@@ -141,4 +141,74 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     return 0;
 }
 
+
+// ---- step-wise API: lets the multi-process (gloo) tests drive one replica per rank exactly
+// the way the HIP engine is driven per pivot (price shard -> all-gather -> pivot).
+void* emul_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, const int64_t* cost,
+                  const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size) {
+    Emul* e = new Emul();
+    e->rule = rule;
+    int err = 0;
+    std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e->im, &err);
+    if (err) { std::fprintf(stderr, "emul_create: %s\n", msg.c_str()); delete e; return nullptr; }
+    bind(*e);
+    McfCtx& c = e->ctx;
+    c.max_pivots = INT64_MAX;
+    if (block_size <= 0) block_size = m < 1000 ? m / 4 : (m < 10000 ? m / 8 : m / 16);
+    if (block_size < 1) block_size = 1;
+    c.block_size = rule == MCF_RULE_DEVEX_BLOCK ? block_size : (m > 0 ? m : 1);
+    c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
+    if (c.num_blocks < 1) c.num_blocks = 1;
+    return e;
+}
+
+// best candidate of arcs [lo, hi) (intersected with the current Devex block)
+void emul_price(void* h, int64_t lo, int64_t hi, int64_t* key_arc /*[2]*/) {
+    Emul* e = static_cast<Emul*>(h);
+    const McfCtx& c = e->ctx;
+    if (e->rule == MCF_RULE_DEVEX_BLOCK) {
+        const int64_t bs = c.block_start, be = bs + c.block_size;
+        lo = lo > bs ? lo : bs;
+        hi = hi < be ? hi : be;
+    }
+    if (hi > e->im.m) hi = e->im.m;
+    key_arc[0] = 0; key_arc[1] = -1;
+    if (c.status == MCF_RUNNING && lo < hi) price(*e, lo, hi, &key_arc[0], &key_arc[1]);
+}
+
+// apply the best of `ncand` (key, arc) candidates, like k_pivot + k_apply
+void emul_pivot(void* h, const int64_t* cands, int32_t ncand) {
+    Emul* e = static_cast<Emul*>(h);
+    McfCtx& c = e->ctx;
+    if (c.status != MCF_RUNNING) return;
+    int64_t key = 0, arc = -1;
+    for (int32_t i = 0; i < ncand; ++i)
+        if (mcf_cand_better(cands[2 * i], cands[2 * i + 1], key, arc)) { key = cands[2 * i]; arc = cands[2 * i + 1]; }
+    mcf_pivot_seq(e->view, key, arc, e->rule);
+    if (c.apply) {
+        for (int32_t j = c.lo; j < c.hi; ++j) mcf_apply_one(e->view, c, j);
+        for (int32_t j = c.prev_lo; j < c.prev_hi; ++j)
+            if (j < c.lo || j >= c.hi) mcf_apply_one(e->view, c, j);
+    }
+}
+
+void emul_set_max_pivots(void* h, int64_t cap) {
+    Emul* e = static_cast<Emul*>(h);
+    e->ctx.max_pivots = cap;
+    if (e->ctx.status == MCF_PIVOT_LIMIT && e->ctx.pivots < cap) e->ctx.status = MCF_RUNNING;
+}
+
+// status: -1 running, else MCF_ST_* numbering (infeasible resolved from the artificial flow)
+void emul_poll(void* h, int32_t* status, int64_t* pivots, int64_t* objective_hi_lo, int64_t* flow) {
+    Emul* e = static_cast<Emul*>(h);
+    McfHostResult r;
+    mcf_extract(e->im, e->im.arcw, e->ctx.status, r);
+    *status = e->ctx.status == MCF_RUNNING ? -1 : r.status;
+    *pivots = e->ctx.pivots;
+    if (objective_hi_lo) { objective_hi_lo[0] = (int64_t)(r.objective >> 64); objective_hi_lo[1] = (int64_t)(uint64_t)r.objective; }
+    if (flow) for (int64_t i = 0; i < e->im.m; ++i) flow[i] = e->im.arcw[i].flow;
+}
+
+void emul_destroy(void* h) { delete static_cast<Emul*>(h); }
+
 }  // extern "C"
