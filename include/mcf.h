@@ -74,8 +74,8 @@ typedef struct mcf_options {
     int32_t use_graph;       /* 1 = replay a captured hipGraph of batch_pivots pivots */
     int32_t profile;         /* 1 = bracket every kernel with HIP events (no graph), fills *_ms */
     int64_t block_size;      /* Devex block size; 0 = auto (simplex_adaptive.py:89-96) */
-    int64_t price_lo;        /* arc shard [price_lo, price_hi) this handle prices; */
-    int64_t price_hi;        /*   both 0 = all arcs.  price_lo must be a multiple of 4. */
+    int64_t shard_rank;      /* multi-GPU: this handle prices shard shard_rank of shard_count */
+    int64_t shard_count;     /*   (0 or 1 = all arcs); a shard is 1/shard_count of every XCD head bucket */
     int32_t price_blocks;    /* pricing grid size; 0 = auto */
     int32_t reserved;
 } mcf_options;
@@ -127,8 +127,8 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
 int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int64_t* flow,
                    int64_t* potential, int8_t* in_tree, mcf_stats* stats);
 
-/* One pricing pass over arcs [start, end) with the current potentials, without pivoting:
- * the kernel-level parity hook.  *arc = -1 when no arc is eligible; *dir = +1 forward /
+/* One pricing pass over arcs [start, end) (caller's arc indices) with the current potentials,
+ * without pivoting: the kernel-level parity hook.  Ties go to the lowest arc index.  *arc = -1 when no arc is eligible; *dir = +1 forward /
  * -1 backward; *key = violation |rc| (Dantzig) or the f64 merit's bit pattern (Devex). */
 int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int64_t* arc, int32_t* dir,
                    int64_t* key);
@@ -137,8 +137,8 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
 int mcf_reset(mcf_handle* h);
 
 /* ---- arc-sharded multi-GPU pivoting: one handle per rank, every rank holds the full
- * replicated state and prices only its shard (options.price_lo/hi).  Per pivot:
- *   mcf_enqueue_price   local best candidate -> cand_out (device, 2 x int64: key, arc)
+ * replicated state and prices only its shard (options.shard_rank / shard_count).  Per pivot:
+ *   mcf_enqueue_price   local best candidate -> cand_out (device, 2 x int64: key, packed arc id)
  *   <RCCL all-gather of the 16-byte candidates, by the caller, on the same stream>
  *   mcf_enqueue_pivot   every rank applies the same winning pivot to its replica
  * `stream` is a hipStream_t (0 = default stream).  Nothing here synchronises. */

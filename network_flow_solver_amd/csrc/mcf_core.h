@@ -60,11 +60,16 @@ struct alignas(16) McfArcW {
     int64_t flow;
 };
 
-// Entering-arc candidate: larger key wins, ties -> smaller arc index.
+// Entering-arc candidate: larger key wins, ties -> smaller `arc` word.
+// `arc` packs (caller's original arc index << 32) | engine arc index, so ties fall to the
+// lowest ORIGINAL index: the pivot sequence does not depend on the engine's internal arc
+// layout (mcf_host.h permutes arcs into XCD head buckets).
 struct alignas(16) McfCand {
     int64_t key;   // Dantzig: violation = -state*rc > 0;  Devex: bit pattern of the f64 merit;  <= 0: none
-    int64_t arc;   // global arc index, -1 when none
+    int64_t arc;   // packed ids, -1 when none
 };
+
+#define MCF_NUM_BUCKETS 8  // one head-node bucket per XCD (8 XCDs, private 4 MiB L2 each)
 
 // Segment of the block permutation that re-roots the moved subtree:
 // new positions [dst, dst+len) take old positions [src, src+len).
@@ -85,9 +90,9 @@ struct McfCtx {
     int64_t nodes_moved;       // sum of preorder positions rewritten (diagnostic)
     int64_t subtree_nodes;     // sum of |T2| (diagnostic)
     int64_t cycle_arcs;        // sum of cycle lengths (diagnostic)
-    // ---- block-search state (Devex rule)
-    int64_t block_size;
-    int64_t block_start;       // first arc of the block the next pricing pass scans
+    // ---- block-search state (Devex rule): block k = slice k of every bucket
+    int64_t block_size;        // nominal arcs per block (reporting only)
+    int64_t block_index;       // block the next pricing pass scans
     int32_t empty_blocks;      // consecutive blocks without a candidate
     int32_t num_blocks;
     // ---- preorder double buffer
@@ -107,9 +112,11 @@ struct McfCtx {
 struct McfView {
     int32_t n_nodes;        // including the artificial root (= n_nodes - 1)
     int64_t m;              // real arcs; artificial arc of node v is m + v
-    const int32_t* tail;    // [m_pad]
+    const int32_t* tail;    // [m_pad]  arcs in ENGINE order: bucketed by head range, tail-sorted inside
     const int32_t* head;    // [m_pad]
     const int32_t* cost;    // [m_pad]
+    const int32_t* orig;    // [m_pad]  engine arc index -> caller's arc index
+    int64_t bucket_off[MCF_NUM_BUCKETS + 1];  // engine arcs of bucket x: [bucket_off[x], bucket_off[x+1])
     int8_t* state;          // [m_pad]  +1 at lower bound, -1 at upper bound, 0 basic / padding
     float* weight;          // [m_pad]  Devex reference weights (nullptr for Dantzig)
     McfArcW* arcw;          // [m + n_nodes - 1]
@@ -124,6 +131,22 @@ struct McfView {
 
 MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc) {
     return key > bkey || (key == bkey && key > 0 && arc < barc);
+}
+
+MCF_HD int64_t mcf_pack_arc(int32_t orig, int64_t engine_idx) { return ((int64_t)orig << 32) | engine_idx; }
+
+// The arcs one pricing pass of one rank looks at inside bucket x: the Devex block k of nb
+// (a Devex "block" is slice k of every bucket, so a block search spans all 8 XCDs), and of
+// that block the rank's share r of G (every GPU keeps all its XCDs busy).  Block first, shard
+// second: the union over ranks is the same arc set for any number of GPUs, so the pivot
+// sequence does not depend on the GPU count.
+MCF_HD void mcf_bucket_slice(const int64_t* bucket_off, int x, int64_t r, int64_t G, int64_t k, int64_t nb,
+                             int64_t* lo, int64_t* hi) {
+    const int64_t s = bucket_off[x], len = bucket_off[x + 1] - s;
+    const int64_t a = s + len * k / nb, b = s + len * (k + 1) / nb;
+    const int64_t len2 = b - a;
+    *lo = a + len2 * r / G;
+    *hi = a + len2 * (r + 1) / G;
 }
 
 // Reduced cost of arc i under the current potentials (simplex.py:508-512):
@@ -158,8 +181,8 @@ MCF_HD void mcf_pivot_seq(const McfView& v, int64_t best_key, int64_t best_arc, 
         if (rule == MCF_RULE_DEVEX_BLOCK) {
             // this block held no eligible arc: move on (simplex_pricing.py:325-355)
             c->empty_blocks += 1;
-            c->block_start += c->block_size;
-            if (c->block_start >= v.m) c->block_start = 0;
+            c->block_index += 1;
+            if (c->block_index >= c->num_blocks) c->block_index = 0;
             if (c->empty_blocks >= c->num_blocks) c->status = MCF_OPTIMAL;
         } else {
             c->status = MCF_OPTIMAL;
@@ -168,7 +191,7 @@ MCF_HD void mcf_pivot_seq(const McfView& v, int64_t best_key, int64_t best_arc, 
     }
     c->empty_blocks = 0;
 
-    const int32_t e = (int32_t)best_arc;
+    const int32_t e = (int32_t)(best_arc & 0xffffffff);  // engine index (low word of the packed id)
     const int32_t s = v.state[e];  // +1: flow rises from 0; -1: flow falls from cap
     const int32_t first = s > 0 ? v.tail[e] : v.head[e];
     const int32_t second = s > 0 ? v.head[e] : v.tail[e];

@@ -16,7 +16,7 @@
 //             BFS rebuild (basis.py:82-122) and _update_tree_sets (simplex.py:1103-1107).
 //
 // The host enqueues `batch_pivots` pivots (optionally as one captured hipGraph), then
-// reads the 200-byte control block back once.  Kernels of a finished solve early-exit.
+// reads the small control block back once.  Kernels of a finished solve early-exit.
 //
 // gfx950 only; no CPU path: without a device every compute entry point returns
 // MCF_E_NO_DEVICE.
@@ -40,6 +40,10 @@ constexpr int kPivotThreads = 256;
 constexpr int kApplyThreads = 256;
 constexpr int kMaxPriceBlocks = 2048;  // 8 workgroups per CU on 256 CUs
 constexpr int kMaxApplyBlocks = 512;
+#ifndef MCF_PRICE_UNROLL
+#define MCF_PRICE_UNROLL 2
+#endif
+constexpr int kUnroll = MCF_PRICE_UNROLL;  // 4-arc groups in flight per lane in k_price
 
 thread_local std::string g_create_error;
 
@@ -70,51 +74,88 @@ __device__ __forceinline__ void block_argmax(int64_t& key, int64_t& arc) {
 }
 
 // ------------------------------------------------------------------ k_price
-// Each lane owns groups of 4 consecutive arcs (one 16-byte load per SoA stream).
-// range: [lo, hi) is this handle's shard; with USE_BLOCK the Devex block
-// [ctx.block_start, +block_size) is intersected with it on the device, so the host
-// never has to know where the block search currently stands.
-template <int RULE>
-__global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t lo, int64_t hi, int use_block,
-                                                          McfCand* __restrict__ cand) {
+// XCD-aware sweep.  Workgroups are dealt to XCDs round-robin (blockIdx % 8 share an XCD --
+// a performance observation, not a correctness assumption), so workgroup b sweeps head-bucket
+// b % 8: its random pi[head] gathers stay inside one eighth of the potential array, which the
+// XCD's private L2 holds; pi[tail] runs almost sequentially (arcs are tail-sorted inside a
+// bucket) and coalesces.  Each lane owns groups of 4 consecutive arcs: one 16-byte load per
+// SoA stream (tail, head, cost[, weight]) + 4 state bytes = 13 (17) B per arc.
+// Inside the bucket the pass covers the rank's shard and, for Devex, the current block
+// (mcf_bucket_slice), both resolved on the device so a captured graph can be replayed.
+// FILTER restricts the pass to arcs whose ORIGINAL index lies in [f_lo, f_hi) (parity hook).
+template <int RULE, bool FILTER>
+__global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shard, int64_t shards, int use_block,
+                                                          int64_t f_lo, int64_t f_hi, McfCand* __restrict__ cand) {
     int64_t key = 0, arc = -1;
     const McfCtx* c = v.ctx;
     if (c->status == MCF_RUNNING) {
-        if (use_block) {
-            const int64_t bs = c->block_start, be = bs + c->block_size;
-            lo = lo > bs ? lo : bs;
-            hi = hi < be ? hi : be;
-        }
+        const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
+        const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+        int64_t lo, hi;
+        mcf_bucket_slice(v.bucket_off, x, shard, shards, use_block ? c->block_index : 0, use_block ? c->num_blocks : 1,
+                         &lo, &hi);
         const int64_t g_lo = lo >> 2, g_hi = (hi + 3) >> 2;  // groups of 4 arcs
         const int4* __restrict__ tail4 = reinterpret_cast<const int4*>(v.tail);
         const int4* __restrict__ head4 = reinterpret_cast<const int4*>(v.head);
         const int4* __restrict__ cost4 = reinterpret_cast<const int4*>(v.cost);
         const int32_t* __restrict__ state4 = reinterpret_cast<const int32_t*>(v.state);
         const float4* __restrict__ w4 = reinterpret_cast<const float4*>(v.weight);
+        const int32_t* __restrict__ orig = v.orig;
         const int64_t* __restrict__ pi = v.pi;
-        const int64_t stride = (int64_t)gridDim.x * kPriceThreads;
-        for (int64_t g = g_lo + (int64_t)blockIdx.x * kPriceThreads + threadIdx.x; g < g_hi; g += stride) {
-            const int32_t st = state4[g];
-            if (st == 0) continue;  // four basic / padding arcs: nothing to gather
-            const int4 t = tail4[g], h = head4[g], cc = cost4[g];
-            float4 w = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (RULE == MCF_RULE_DEVEX_BLOCK) w = w4[g];
-            const int32_t ts[4] = {t.x, t.y, t.z, t.w}, hs[4] = {h.x, h.y, h.z, h.w}, cs[4] = {cc.x, cc.y, cc.z, cc.w};
-            const float ws[4] = {w.x, w.y, w.z, w.w};
+        const int64_t stride = nlb * kPriceThreads;
+        // kUnroll groups of 4 arcs in flight per lane: all SoA loads are issued first, then all
+        // 8 * kUnroll potential gathers, so a wave exposes one memory round trip per phase
+        // instead of one per group (the sweep is latency-bound otherwise).
+        for (int64_t g0 = g_lo + lb * kPriceThreads + threadIdx.x; g0 < g_hi; g0 += stride * kUnroll) {
+            int32_t st[kUnroll];
+            int4 t[kUnroll], h[kUnroll], cc[kUnroll];
+            float4 w[kUnroll];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int32_t s = (int32_t)(int8_t)(st >> (8 * k));
-                const int64_t i = (g << 2) + k;
-                if (s == 0 || i < lo || i >= hi) continue;
-                const int64_t rc = (int64_t)cs[k] + pi[ts[k]] - pi[hs[k]];
-                const int64_t viol = -(int64_t)s * rc;
-                if (viol <= 0) continue;
-                int64_t kk = viol;
-                if (RULE == MCF_RULE_DEVEX_BLOCK) {
-                    const double merit = ((double)viol * (double)viol) / (double)ws[k];
-                    kk = __double_as_longlong(merit);
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t g = g0 + u * stride;
+                const bool in = g < g_hi;
+                st[u] = in ? state4[g] : 0;
+                const int64_t gs = in ? g : g_lo;  // clamp: keep the loads unconditional and in range
+                t[u] = tail4[gs];
+                h[u] = head4[gs];
+                cc[u] = cost4[gs];
+                if (RULE == MCF_RULE_DEVEX_BLOCK) w[u] = w4[gs];
+            }
+            int64_t pt[kUnroll][4], ph[kUnroll][4];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int32_t ts[4] = {t[u].x, t[u].y, t[u].z, t[u].w}, hs[4] = {h[u].x, h[u].y, h[u].z, h[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool live = ((st[u] >> (8 * k)) & 0xff) != 0;
+                    pt[u][k] = live ? pi[ts[k]] : 0;
+                    ph[u][k] = live ? pi[hs[k]] : 0;
                 }
-                if (mcf_cand_better(kk, i, key, arc)) { key = kk; arc = i; }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int32_t cs[4] = {cc[u].x, cc[u].y, cc[u].z, cc[u].w};
+                const float ws[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+                const int64_t g = g0 + u * stride;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t s = (int32_t)(int8_t)(st[u] >> (8 * k));
+                    const int64_t i = (g << 2) + k;
+                    if (s == 0 || i < lo || i >= hi) continue;
+                    const int64_t rc = (int64_t)cs[k] + pt[u][k] - ph[u][k];
+                    const int64_t viol = -(int64_t)s * rc;
+                    if (viol <= 0) continue;
+                    int64_t kk = viol;
+                    if (RULE == MCF_RULE_DEVEX_BLOCK) {
+                        const double merit = ((double)viol * (double)viol) / (double)ws[k];
+                        kk = __double_as_longlong(merit);
+                    }
+                    if (kk < key) continue;              // cannot win: skip the id lookup
+                    const int32_t o = orig[i];
+                    if (FILTER && (o < f_lo || o >= f_hi)) continue;
+                    const int64_t id = mcf_pack_arc(o, i);
+                    if (mcf_cand_better(kk, id, key, arc)) { key = kk; arc = id; }
+                }
             }
         }
     }
@@ -185,7 +226,7 @@ struct mcf_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     // device arrays
-    int32_t *d_tail = nullptr, *d_head = nullptr, *d_cost = nullptr;
+    int32_t *d_tail = nullptr, *d_head = nullptr, *d_cost = nullptr, *d_orig = nullptr;
     int8_t* d_state = nullptr;
     float* d_weight = nullptr;
     McfArcW* d_arcw = nullptr;
@@ -201,7 +242,8 @@ struct mcf_handle {
     McfView view{};
     int price_blocks = 1;
     int apply_blocks = 1;
-    int64_t price_lo = 0, price_hi = 0;
+    int64_t shard = 0, shards = 1;
+    int64_t shard_arcs = 0;  // arcs of this rank's shard (all buckets)
     int64_t priced_per_pass = 0;
     // graph
     hipGraph_t graph = nullptr;
@@ -241,6 +283,7 @@ int upload_image(mcf_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->d_tail, im.tail.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_head, im.head.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_cost, im.cost.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_orig, im.orig.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_state, im.state.data(), im.m_pad, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_weight, im.weight.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_arcw, im.arcw.data(), im.arcw.size() * sizeof(McfArcW), hipMemcpyHostToDevice, h->stream));
@@ -262,8 +305,13 @@ int upload_image(mcf_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->d_ctx, h->h_ctx, sizeof(McfCtx), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     // per-pass accounting: a Devex pass prices one block of the shard, Dantzig the whole shard
-    const int64_t shard = h->price_hi - h->price_lo;
-    h->priced_per_pass = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? (c.block_size < shard ? c.block_size : shard) : shard;
+    h->shard_arcs = 0;
+    for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+        int64_t lo, hi;
+        mcf_bucket_slice(im.bucket_off, x, h->shard, h->shards, 0, 1, &lo, &hi);
+        h->shard_arcs += hi - lo;
+    }
+    h->priced_per_pass = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? (h->shard_arcs + c.num_blocks - 1) / c.num_blocks : h->shard_arcs;
     std::memset(&h->stats, 0, sizeof h->stats);
     h->stats.unbounded_arc = -1;
     h->stats.price_bytes = (h->opt.rule == MCF_RULE_DEVEX_BLOCK ? 17 : 13) * h->priced_per_pass + 8 * (int64_t)im.n_nodes;
@@ -272,18 +320,18 @@ int upload_image(mcf_handle* h) {
     return MCF_OK;
 }
 
-void launch_price(mcf_handle* h, hipStream_t s, int32_t rule, int64_t lo, int64_t hi, int use_block) {
+void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, int use_block) {
     if (rule == MCF_RULE_DEVEX_BLOCK)
-        hipLaunchKernelGGL(k_price<MCF_RULE_DEVEX_BLOCK>, dim3(h->price_blocks), dim3(kPriceThreads), 0, s, h->view, lo, hi,
-                           use_block, h->d_cand);
+        hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, false>), dim3(h->price_blocks), dim3(kPriceThreads), 0, s, v, h->shard,
+                           h->shards, use_block, (int64_t)0, (int64_t)0, h->d_cand);
     else
-        hipLaunchKernelGGL(k_price<MCF_RULE_DANTZIG>, dim3(h->price_blocks), dim3(kPriceThreads), 0, s, h->view, lo, hi, 0,
-                           h->d_cand);
+        hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, false>), dim3(h->price_blocks), dim3(kPriceThreads), 0, s, v, h->shard,
+                           h->shards, 0, (int64_t)0, (int64_t)0, h->d_cand);
 }
 
 void launch_pivot_triplet(mcf_handle* h, hipStream_t s) {
     const int32_t rule = h->opt.rule;
-    launch_price(h, s, rule, h->price_lo, h->price_hi, rule == MCF_RULE_DEVEX_BLOCK);
+    launch_price(h, s, h->view, rule, rule == MCF_RULE_DEVEX_BLOCK);
     hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, h->d_cand, h->price_blocks, rule,
                        h->priced_per_pass);
     hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
@@ -313,7 +361,7 @@ int run_batch_profiled(mcf_handle* h, int batch) {
     for (int i = 0; i < batch; ++i) {
         hipEvent_t* ev = &h->events[(size_t)i * 4];
         HIP_TRY(h, hipEventRecord(ev[0], h->stream));
-        launch_price(h, h->stream, rule, h->price_lo, h->price_hi, rule == MCF_RULE_DEVEX_BLOCK);
+        launch_price(h, h->stream, h->view, rule, rule == MCF_RULE_DEVEX_BLOCK);
         HIP_TRY(h, hipEventRecord(ev[1], h->stream));
         hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, h->stream, h->view, h->d_cand, h->price_blocks, rule,
                            h->priced_per_pass);
@@ -344,7 +392,7 @@ void free_all(mcf_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
+    (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_one);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
@@ -396,19 +444,22 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     }
     if (hipGetDevice(&h->device) != hipSuccess) { g_create_error = "hipGetDevice failed"; delete h; return MCF_E_HIP; }
     // shard
-    h->price_lo = opt.price_lo;
-    h->price_hi = (opt.price_lo == 0 && opt.price_hi == 0) ? m : opt.price_hi;
-    if (h->price_lo < 0 || h->price_hi > m || h->price_lo > h->price_hi || (h->price_lo & 3)) {
-        g_create_error = "bad price_lo/price_hi (0 <= lo <= hi <= m, lo multiple of 4)";
+    h->shards = opt.shard_count > 0 ? opt.shard_count : 1;
+    h->shard = opt.shard_rank;
+    if (h->shard < 0 || h->shard >= h->shards) {
+        g_create_error = "bad shard_rank / shard_count";
         delete h;
         return MCF_E_BAD_ARG;
     }
     const McfHostImage& im = h->im;
-    const int64_t shard_groups = ((h->price_hi - h->price_lo) + 1023) / 1024;  // 256 lanes x 4 arcs per block pass
-    int pb = opt.price_blocks > 0 ? opt.price_blocks : (int)(shard_groups < kMaxPriceBlocks ? shard_groups : kMaxPriceBlocks);
-    if (pb < 1) pb = 1;
-    h->price_blocks = pb;
     {
+        // 256 lanes x 4 arcs per workgroup pass; a multiple of 8 workgroups so every XCD bucket is covered
+        const int64_t per_pass = (int64_t)kPriceThreads * 4 * kUnroll;
+        const int64_t per_bucket = (m / h->shards / MCF_NUM_BUCKETS + per_pass - 1) / per_pass;
+        int64_t pb = opt.price_blocks > 0 ? (opt.price_blocks + 7) / 8 : per_bucket;
+        if (pb < 1) pb = 1;
+        if (pb > kMaxPriceBlocks / MCF_NUM_BUCKETS) pb = kMaxPriceBlocks / MCF_NUM_BUCKETS;
+        h->price_blocks = (int)pb * MCF_NUM_BUCKETS;
         const int64_t ab = ((int64_t)im.n_nodes + kApplyThreads - 1) / kApplyThreads;
         h->apply_blocks = (int)(ab < kMaxApplyBlocks ? ab : kMaxApplyBlocks);
     }
@@ -425,6 +476,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     if ((e = dalloc(&h->d_tail, im.m_pad)) != hipSuccess) return fail("hipMalloc tail", e);
     if ((e = dalloc(&h->d_head, im.m_pad)) != hipSuccess) return fail("hipMalloc head", e);
     if ((e = dalloc(&h->d_cost, im.m_pad)) != hipSuccess) return fail("hipMalloc cost", e);
+    if ((e = dalloc(&h->d_orig, im.m_pad)) != hipSuccess) return fail("hipMalloc orig", e);
     if ((e = dalloc(&h->d_state, im.m_pad)) != hipSuccess) return fail("hipMalloc state", e);
     if ((e = dalloc(&h->d_weight, im.m_pad)) != hipSuccess) return fail("hipMalloc weight", e);
     if ((e = dalloc(&h->d_arcw, im.arcw.size())) != hipSuccess) return fail("hipMalloc arcw", e);
@@ -444,7 +496,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     McfView& v = h->view;
     v.n_nodes = im.n_nodes;
     v.m = im.m;
-    v.tail = h->d_tail; v.head = h->d_head; v.cost = h->d_cost; v.state = h->d_state;
+    v.tail = h->d_tail; v.head = h->d_head; v.cost = h->d_cost; v.orig = h->d_orig; v.state = h->d_state;
+    for (int x = 0; x <= MCF_NUM_BUCKETS; ++x) v.bucket_off[x] = im.bucket_off[x];
     v.weight = opt.rule == MCF_RULE_DEVEX_BLOCK ? h->d_weight : nullptr;
     v.arcw = h->d_arcw; v.pi = h->d_pi; v.node = h->d_node;
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
@@ -557,7 +610,7 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
         objective_hi_lo[0] = (int64_t)(r.objective >> 64);
         objective_hi_lo[1] = (int64_t)(uint64_t)r.objective;
     }
-    if (flow) for (int64_t i = 0; i < im.m; ++i) flow[i] = arcw[i].flow;
+    if (flow) for (int64_t i = 0; i < im.m; ++i) flow[im.orig[i]] = arcw[i].flow;  // engine order -> caller's
     if (potential) {
         std::vector<int64_t> pi(im.n_nodes);
         HIP_TRY(h, hipMemcpy(pi.data(), h->d_pi, pi.size() * 8, hipMemcpyDeviceToHost));
@@ -566,14 +619,14 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
     if (in_tree) {
         std::vector<int8_t> st(im.m_pad);
         HIP_TRY(h, hipMemcpy(st.data(), h->d_state, st.size(), hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < im.m; ++i) in_tree[i] = st[i] == 0;
+        for (int64_t i = 0; i < im.m; ++i) in_tree[im.orig[i]] = st[i] == 0;
     }
     if (stats) {
         const McfCtx& c = *h->h_ctx;
         h->stats.pivots = c.pivots; h->stats.degenerate = c.degenerate; h->stats.bound_flips = c.bound_flips;
         h->stats.arcs_priced = c.arcs_priced; h->stats.nodes_moved = c.nodes_moved;
         h->stats.subtree_nodes = c.subtree_nodes; h->stats.cycle_arcs = c.cycle_arcs;
-        h->stats.unbounded_arc = c.unbounded_arc;
+        h->stats.unbounded_arc = c.unbounded_arc >= 0 ? im.orig[c.unbounded_arc] : -1;
         h->stats.artificial_flow = r.artificial_flow;
         h->stats.unbounded_rc = 0;
         if (c.status == MCF_UNBOUNDED && c.unbounded_arc >= 0) {
@@ -601,22 +654,26 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
     const int32_t saved = h->h_ctx->status;
     int32_t running = MCF_RUNNING;
     HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &running, 4, hipMemcpyHostToDevice, h->stream));
+    // whole arc list (shard 0 of 1), restricted to ORIGINAL indices [start, end)
     if (rule == MCF_RULE_DEVEX_BLOCK)
-        hipLaunchKernelGGL(k_price<MCF_RULE_DEVEX_BLOCK>, dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v, start, end, 0, h->d_cand);
+        hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, true>), dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v,
+                           (int64_t)0, (int64_t)1, 0, start, end, h->d_cand);
     else
-        hipLaunchKernelGGL(k_price<MCF_RULE_DANTZIG>, dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v, start, end, 0, h->d_cand);
+        hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, true>), dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v,
+                           (int64_t)0, (int64_t)1, 0, start, end, h->d_cand);
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, h->stream, h->d_cand, h->price_blocks, h->d_one);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &saved, 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_one, h->d_one, sizeof(McfCand), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    *arc = h->h_one->key > 0 ? h->h_one->arc : -1;
-    if (key) *key = h->h_one->key > 0 ? h->h_one->key : 0;
+    const bool found = h->h_one->key > 0 && h->h_one->arc >= 0;
+    *arc = found ? (h->h_one->arc >> 32) : -1;  // caller's arc index
+    if (key) *key = found ? h->h_one->key : 0;
     if (dir) {
         *dir = 0;
-        if (*arc >= 0) {
+        if (found) {
             int8_t st = 0;
-            HIP_TRY(h, hipMemcpy(&st, h->d_state + *arc, 1, hipMemcpyDeviceToHost));
+            HIP_TRY(h, hipMemcpy(&st, h->d_state + (h->h_one->arc & 0xffffffff), 1, hipMemcpyDeviceToHost));
             *dir = st;
         }
     }
@@ -627,7 +684,7 @@ int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev) {
     if (!h || !cand_out_dev) return MCF_E_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int32_t rule = h->opt.rule;
-    launch_price(h, s, rule, h->price_lo, h->price_hi, rule == MCF_RULE_DEVEX_BLOCK);
+    launch_price(h, s, h->view, rule, rule == MCF_RULE_DEVEX_BLOCK);
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, s, h->d_cand, h->price_blocks,
                        reinterpret_cast<McfCand*>(cand_out_dev));
     HIP_TRY(h, hipGetLastError());
@@ -638,7 +695,8 @@ int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int
     if (!h || !cands_dev || ncand < 1) return MCF_E_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // every rank accounts the arcs of ALL shards, so arcs_priced is the whole-job figure
-    const int64_t priced = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? h->h_ctx->block_size : h->im.m;
+    const int64_t nblk = h->h_ctx->num_blocks > 0 ? h->h_ctx->num_blocks : 1;
+    const int64_t priced = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? (h->im.m + nblk - 1) / nblk : h->im.m;
     hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, reinterpret_cast<const McfCand*>(cands_dev), ncand,
                        h->opt.rule, priced);
     hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
@@ -674,12 +732,7 @@ int mcf_time_pricing(mcf_handle* h, int32_t rule, int32_t reps, double* ms_per_l
     hipEvent_t e0, e1;
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
-    auto once = [&]() {
-        if (rule == MCF_RULE_DEVEX_BLOCK)
-            hipLaunchKernelGGL(k_price<MCF_RULE_DEVEX_BLOCK>, dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v, h->price_lo, h->price_hi, 1, h->d_cand);
-        else
-            hipLaunchKernelGGL(k_price<MCF_RULE_DANTZIG>, dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v, h->price_lo, h->price_hi, 0, h->d_cand);
-    };
+    auto once = [&]() { launch_price(h, h->stream, v, rule, rule == MCF_RULE_DEVEX_BLOCK); };
     once();  // warm
     HIP_TRY(h, hipEventRecord(e0, h->stream));
     for (int i = 0; i < reps; ++i) once();
@@ -732,7 +785,10 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
     HIP_TRY(h, hipMemcpy(nodes.data(), h->d_node, nodes.size() * sizeof(McfNode), hipMemcpyDeviceToHost));
     for (int32_t v = 0; v < im.n_nodes; ++v) {
         if (parent) parent[v] = nodes[v].parent;
-        if (pred_arc) pred_arc[v] = nodes[v].pred < 0 ? -1 : nodes[v].pred >> 1;
+        if (pred_arc) {
+            const int64_t a = nodes[v].pred < 0 ? -1 : nodes[v].pred >> 1;
+            pred_arc[v] = a < 0 ? -1 : (a < im.m ? im.orig[a] : (int32_t)a);  // artificial arcs keep m + node
+        }
         if (size) size[v] = nodes[v].size;
         if (pos) pos[v] = nodes[v].pos;
     }
@@ -740,7 +796,11 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
         const int cur = h->h_ctx->cur ^ (h->h_ctx->pending_flip ? 1 : 0);
         HIP_TRY(h, hipMemcpy(order, cur ? h->d_order1 : h->d_order0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
     }
-    if (state) HIP_TRY(h, hipMemcpy(state, h->d_state, (size_t)im.m, hipMemcpyDeviceToHost));
+    if (state) {
+        std::vector<int8_t> st(im.m_pad);
+        HIP_TRY(h, hipMemcpy(st.data(), h->d_state, st.size(), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < im.m; ++i) state[im.orig[i]] = st[i];
+    }
     if (potential_with_root) HIP_TRY(h, hipMemcpy(potential_with_root, h->d_pi, (size_t)im.n_nodes * 8, hipMemcpyDeviceToHost));
     return MCF_OK;
 }

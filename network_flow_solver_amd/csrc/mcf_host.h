@@ -21,8 +21,10 @@ struct McfHostImage {
     int64_t m = 0;          // real arcs
     int64_t m_pad = 0;      // m rounded up to a multiple of 1024 (padding arcs have state 0)
     int64_t big_m = 0;
-    std::vector<int32_t> tail, head, cost;  // [m_pad]
-    std::vector<int64_t> cost64;            // [m] exact costs for the objective
+    std::vector<int32_t> tail, head, cost;  // [m_pad]  ENGINE order (see mcf_build_image)
+    std::vector<int32_t> orig;              // [m_pad]  engine arc index -> caller's arc index
+    int64_t bucket_off[MCF_NUM_BUCKETS + 1] = {0};
+    std::vector<int64_t> cost64;            // [m] exact costs for the objective (engine order)
     std::vector<int8_t> state;              // [m_pad]
     std::vector<float> weight;              // [m_pad]
     std::vector<McfArcW> arcw;              // [m + n]
@@ -33,9 +35,17 @@ struct McfHostImage {
 };
 
 // Validate the caller's arrays and build the start basis.  Returns "" or an error text.
+//
+// Arc layout ("engine order"): arcs are bucketed by the node range their HEAD falls in --
+// MCF_NUM_BUCKETS = 8 ranges, one per XCD -- and sorted by tail inside a bucket (stable, so
+// equal tails keep the caller's order).  The pricing kernel lets the workgroups of XCD x
+// sweep bucket x: the random head gathers then stay inside 1/8 of the potential array, which
+// fits that XCD's private 4 MiB L2 up to ~4M nodes, while the tail gathers run through pi
+// almost sequentially (and coalesce).  `bucketed = false` keeps the caller's order and cuts
+// it into 8 equal slices instead (used by tests to show results do not depend on the layout).
 inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, const int32_t* head,
                                    const int64_t* cost, const int64_t* cap, const int64_t* supply,
-                                   McfHostImage& im, int* err_code) {
+                                   McfHostImage& im, int* err_code, bool bucketed = true) {
     *err_code = -1;  // MCF_E_BAD_ARG
     if (n < 1) return "n must be >= 1";
     if (m < 0) return "m must be >= 0";
@@ -50,6 +60,7 @@ inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, co
     im.tail.assign(im.m_pad, 0);
     im.head.assign(im.m_pad, 0);
     im.cost.assign(im.m_pad, 0);
+    im.orig.assign(im.m_pad, 0);
     im.cost64.assign(m, 0);
     im.state.assign(im.m_pad, 0);
     im.weight.assign(im.m_pad, 1.0f);
@@ -64,14 +75,42 @@ inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, co
         if (tail[i] == head[i]) return "self-loop";
         const int64_t c = cost[i];
         if (c > INT32_MAX || c < -(int64_t)INT32_MAX) { *err_code = -5; return "|cost| must fit int32"; }
+    }
+
+    // engine order: stable counting sort by tail, then stable distribution into head buckets
+    std::vector<int32_t> perm(m);
+    if (bucketed && m > 0) {
+        std::vector<int64_t> cnt((size_t)n + 1, 0);
+        for (int64_t i = 0; i < m; ++i) cnt[tail[i] + 1]++;
+        for (int32_t v = 0; v < n; ++v) cnt[v + 1] += cnt[v];
+        std::vector<int32_t> by_tail(m);
+        for (int64_t i = 0; i < m; ++i) by_tail[cnt[tail[i]]++] = (int32_t)i;
+        const int64_t per = ((int64_t)n + MCF_NUM_BUCKETS - 1) / MCF_NUM_BUCKETS;
+        int64_t bcnt[MCF_NUM_BUCKETS + 1] = {0};
+        for (int64_t i = 0; i < m; ++i) bcnt[head[i] / per + 1]++;
+        for (int x = 0; x < MCF_NUM_BUCKETS; ++x) bcnt[x + 1] += bcnt[x];
+        for (int x = 0; x <= MCF_NUM_BUCKETS; ++x) im.bucket_off[x] = bcnt[x];
+        for (int64_t j = 0; j < m; ++j) {
+            const int32_t i = by_tail[j];
+            perm[bcnt[head[i] / per]++] = i;
+        }
+    } else {
+        for (int64_t i = 0; i < m; ++i) perm[i] = (int32_t)i;
+        for (int x = 0; x <= MCF_NUM_BUCKETS; ++x) im.bucket_off[x] = m * x / MCF_NUM_BUCKETS;
+    }
+
+    for (int64_t e = 0; e < m; ++e) {
+        const int64_t i = perm[e];
+        const int64_t c = cost[i];
         int64_t cp = cap[i];
         if (cp < 0 || cp >= MCF_INF) cp = MCF_INF;
-        im.tail[i] = tail[i];
-        im.head[i] = head[i];
-        im.cost[i] = (int32_t)c;
-        im.cost64[i] = c;
-        im.state[i] = 1;  // every real arc starts non-basic at its lower bound (flow 0)
-        im.arcw[i] = McfArcW{cp, 0};
+        im.tail[e] = tail[i];
+        im.head[e] = head[i];
+        im.cost[e] = (int32_t)c;
+        im.orig[e] = (int32_t)i;
+        im.cost64[e] = c;
+        im.state[e] = 1;  // every real arc starts non-basic at its lower bound (flow 0)
+        im.arcw[e] = McfArcW{cp, 0};
         const int64_t ac = c < 0 ? -c : c;
         if (ac > max_abs_cost) max_abs_cost = ac;
     }

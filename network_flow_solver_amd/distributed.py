@@ -1,6 +1,7 @@
 """Arc-sharded multi-GPU pivoting: one process per GPU over ``torch.distributed``.
 
-Scheme: the arc list is cut into contiguous shards, one per rank.
+Scheme: the arc list is cut into shards, one per rank (a shard is the
+rank's contiguous 1/world share of each of the eight XCD head buckets).
 Every rank keeps the WHOLE device-resident state (arc SoA, flows, potentials, preorder
 tree -- memory is not the constraint at 288 GB per GPU) but prices only its own shard.
 Per pivot:
@@ -30,13 +31,15 @@ import time
 import numpy as np
 
 
-def shard_bounds(m: int, world: int, rank: int) -> tuple[int, int]:
-    """Contiguous arc range of `rank`; every lower bound is a multiple of 4 (16-byte vector loads)."""
-    def cut(r: int) -> int:
-        if r >= world:
-            return m
-        return min(m, (r * m // world) // 4 * 4)
-    return cut(rank), cut(rank + 1)
+def shard_slices(bucket_off, world: int, rank: int) -> list[tuple[int, int]]:
+    """Engine-order arc ranges of `rank` for a full (Dantzig) sweep: its 1/world share of every
+    XCD head bucket (mcf_bucket_slice in csrc/mcf_core.h with one block), so each GPU keeps all
+    eight XCDs busy."""
+    out = []
+    for x in range(len(bucket_off) - 1):
+        s, length = bucket_off[x], bucket_off[x + 1] - bucket_off[x]
+        out.append((s + length * rank // world, s + length * (rank + 1) // world))
+    return out
 
 
 class HipShardEngine:
@@ -48,9 +51,8 @@ class HipShardEngine:
         from . import engine
 
         self.torch = torch
-        self.lo, self.hi = shard_bounds(inst.m, world, rank)
         self.eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule,
-                                    block_size=block_size, device=device, price_range=(self.lo, self.hi))
+                                    block_size=block_size, device=device, shard=(rank, world))
         self.device = torch.device("cuda", device)
 
     def new_candidate_buffers(self, world: int):
@@ -136,7 +138,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         dt = float(tmax.item())
         pivots = p1 - p0
         sweep_ms = eng.eng.time_pricing(reps=20)
-        shard_arcs = eng.hi - eng.lo
+        shard_arcs = inst.m // world
         bytes_per_launch = 13 * shard_arcs + 8 * (inst.n + 1)
         achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9
         eng.close()

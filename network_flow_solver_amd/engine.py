@@ -17,7 +17,7 @@ import numpy as np
 from .exceptions import NetworkSolverError
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libmcf_hip.so"
+LIB_PATH = Path(os.environ.get("MCF_HIP_LIB", _PKG / "libmcf_hip.so"))  # override: A/B builds of the same ABI
 
 RULE_DANTZIG = 0
 RULE_DEVEX_BLOCK = 1
@@ -48,7 +48,7 @@ class McfOptions(ctypes.Structure):
     _fields_ = [
         ("abi_version", ctypes.c_int32), ("device", ctypes.c_int32), ("rule", ctypes.c_int32),
         ("batch_pivots", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("profile", ctypes.c_int32),
-        ("block_size", ctypes.c_int64), ("price_lo", ctypes.c_int64), ("price_hi", ctypes.c_int64),
+        ("block_size", ctypes.c_int64), ("shard_rank", ctypes.c_int64), ("shard_count", ctypes.c_int64),
         ("price_blocks", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
@@ -139,7 +139,7 @@ class McfEngine:
 
     def __init__(self, n: int, tail, head, cost, cap, supply, rule: int = RULE_DANTZIG, block_size: int = 0,
                  batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
-                 price_range: tuple[int, int] | None = None, price_blocks: int = 0):
+                 shard: tuple[int, int] | None = None, price_blocks: int = 0):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -165,8 +165,8 @@ class McfEngine:
         opt.use_graph = 1 if use_graph else 0
         opt.profile = 1 if profile else 0
         opt.price_blocks = int(price_blocks)
-        if price_range is not None:
-            opt.price_lo, opt.price_hi = int(price_range[0]), int(price_range[1])
+        if shard is not None:
+            opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule
         h = ctypes.c_void_p()
         rc = lib.mcf_create(self.n, self.m, _p(self.tail, ctypes.c_int32), _p(self.head, ctypes.c_int32),

@@ -291,13 +291,14 @@ def _load_emul():
         lib.emul_solve.argtypes = [
             ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, ctypes.c_int32, ctypes.c_int64,
             ctypes.c_int64, i32p, i64p, i64p, i64p, i8p, i64p, i32p, i32p, i32p, i32p, i32p, i64p, ctypes.c_int64,
+            ctypes.c_int32,
         ]
         _emul = lib
     return _emul
 
 
 def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0, max_pivots: int = -1,
-               trace: int = 0) -> dict:
+               trace: int = 0, bucketed: bool = True) -> dict:
     """Run the engine's integer pivot algorithm on the CPU. Arrays are 0-based ints; cap < 0 = inf."""
     lib = _load_emul()
     m = int(len(tail))
@@ -320,7 +321,7 @@ def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int 
         ctypes.byref(status), _ptr(obj, ctypes.c_int64), _ptr(flow, ctypes.c_int64), _ptr(pot, ctypes.c_int64),
         _ptr(in_tree, ctypes.c_int8), _ptr(stats, ctypes.c_int64), _ptr(parent, ctypes.c_int32),
         _ptr(pred, ctypes.c_int32), _ptr(size, ctypes.c_int32), _ptr(pos, ctypes.c_int32),
-        _ptr(order, ctypes.c_int32), _ptr(tr, ctypes.c_int64), trace)
+        _ptr(order, ctypes.c_int32), _ptr(tr, ctypes.c_int64), trace, 1 if bucketed else 0)
     if rc != 0:
         raise RuntimeError(f"emul_solve failed with code {rc}")
     objective = (int(obj[0]) << 64) + (int(obj[1]) & ((1 << 64) - 1))
@@ -338,11 +339,12 @@ class EmulStepper:
     """Step-wise handle on the CPU emulation (one replica): price a shard, apply a pivot.
     Mirrors how the HIP engine is driven per pivot in the arc-sharded multi-GPU loop."""
 
-    def __init__(self, n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0):
+    def __init__(self, n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0, bucketed: bool = True):
         lib = _load_emul()
         i32p, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
         lib.emul_create.restype = ctypes.c_void_p
-        lib.emul_create.argtypes = [ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, ctypes.c_int32, ctypes.c_int64]
+        lib.emul_create.argtypes = [ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, ctypes.c_int32, ctypes.c_int64,
+                                    ctypes.c_int32]
         lib.emul_price.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, i64p]
         lib.emul_price.restype = None
         lib.emul_pivot.argtypes = [ctypes.c_void_p, i64p, ctypes.c_int32]
@@ -361,13 +363,13 @@ class EmulStepper:
         t, h, c, cp, s = self._keep
         self._h = lib.emul_create(int(n), self.m, _ptr(t, ctypes.c_int32), _ptr(h, ctypes.c_int32),
                                   _ptr(c, ctypes.c_int64), _ptr(cp, ctypes.c_int64), _ptr(s, ctypes.c_int64),
-                                  int(rule), int(block_size))
+                                  int(rule), int(block_size), 1 if bucketed else 0)
         if not self._h:
             raise RuntimeError("emul_create failed")
 
-    def price(self, lo: int, hi: int, out: np.ndarray) -> None:
-        """out: int64[2] <- (key, arc) of the best candidate in [lo, hi)."""
-        self._lib.emul_price(self._h, int(lo), int(hi), _ptr(out, ctypes.c_int64))
+    def price(self, shard: int, shards: int, out: np.ndarray) -> None:
+        """out: int64[2] <- (key, packed arc id) of the best candidate in shard `shard` of `shards`."""
+        self._lib.emul_price(self._h, int(shard), int(shards), _ptr(out, ctypes.c_int64))
 
     def pivot(self, cands: np.ndarray, ncand: int) -> None:
         self._lib.emul_pivot(self._h, _ptr(cands, ctypes.c_int64), int(ncand))

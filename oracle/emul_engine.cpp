@@ -41,6 +41,8 @@ void bind(Emul& e) {
     v.tail = im.tail.data();
     v.head = im.head.data();
     v.cost = im.cost.data();
+    v.orig = im.orig.data();
+    for (int x = 0; x <= MCF_NUM_BUCKETS; ++x) v.bucket_off[x] = im.bucket_off[x];
     v.state = im.state.data();
     v.weight = e.rule == MCF_RULE_DEVEX_BLOCK ? im.weight.data() : nullptr;
     v.arcw = im.arcw.data();
@@ -54,23 +56,44 @@ void bind(Emul& e) {
     v.ctx = &e.ctx;
 }
 
-// scalar stand-in for the pricing kernel
-void price(const Emul& e, int64_t lo, int64_t hi, int64_t* key, int64_t* arc) {
+// scalar stand-in for the pricing kernel: shard r of G, Devex block = ctx.block_index of
+// ctx.num_blocks (Dantzig: the single block 0 of 1); same arc set as k_price, same tie rule.
+// Returns the number of arcs looked at.
+int64_t price(const Emul& e, int64_t r, int64_t G, int64_t* key, int64_t* arc) {
     const McfView& v = e.view;
-    int64_t bk = 0, ba = -1;
-    for (int64_t i = lo; i < hi; ++i) {
-        if (!v.state[i]) continue;
-        const int64_t viol = mcf_violation(v, i);
-        if (viol <= 0) continue;
-        int64_t k = viol;
-        if (e.rule == MCF_RULE_DEVEX_BLOCK) {
-            const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
-            std::memcpy(&k, &merit, 8);
+    const int64_t nb = e.rule == MCF_RULE_DEVEX_BLOCK ? v.ctx->num_blocks : 1;
+    const int64_t k = e.rule == MCF_RULE_DEVEX_BLOCK ? v.ctx->block_index : 0;
+    int64_t bk = 0, ba = -1, priced = 0;
+    for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+        int64_t lo, hi;
+        mcf_bucket_slice(v.bucket_off, x, r, G, k, nb, &lo, &hi);
+        priced += hi - lo;
+        for (int64_t i = lo; i < hi; ++i) {
+            if (!v.state[i]) continue;
+            const int64_t viol = mcf_violation(v, i);
+            if (viol <= 0) continue;
+            int64_t kk = viol;
+            if (e.rule == MCF_RULE_DEVEX_BLOCK) {
+                const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
+                std::memcpy(&kk, &merit, 8);
+            }
+            const int64_t id = mcf_pack_arc(v.orig[i], i);
+            if (mcf_cand_better(kk, id, bk, ba)) { bk = kk; ba = id; }
         }
-        if (mcf_cand_better(k, i, bk, ba)) { bk = k; ba = i; }
     }
     *key = bk;
     *arc = ba;
+    return priced;
+}
+
+void init_blocks(Emul& e, int64_t block_size) {
+    McfCtx& c = e.ctx;
+    const int64_t m = e.im.m;
+    if (block_size <= 0) block_size = m < 1000 ? m / 4 : (m < 10000 ? m / 8 : m / 16);  // simplex_adaptive.py:89-96
+    if (block_size < 1) block_size = 1;
+    c.block_size = e.rule == MCF_RULE_DEVEX_BLOCK ? block_size : (m > 0 ? m : 1);
+    c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
+    if (c.num_blocks < 1) c.num_blocks = 1;
 }
 
 }  // namespace
@@ -82,29 +105,23 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
                const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int64_t max_pivots,
                int32_t* status, int64_t* objective_hi_lo, int64_t* flow, int64_t* potential, int8_t* in_tree,
                int64_t* stats /*[10]*/, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
-               int32_t* order, int64_t* trace_arcs, int64_t trace_cap) {
+               int32_t* order, int64_t* trace_arcs, int64_t trace_cap, int32_t bucketed) {
     Emul e;
     e.rule = rule;
     int err = 0;
-    std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e.im, &err);
+    std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e.im, &err, bucketed != 0);
     if (err) { std::fprintf(stderr, "emul_solve: %s\n", msg.c_str()); return err; }
     bind(e);
     McfCtx& c = e.ctx;
     c.max_pivots = max_pivots < 0 ? (20 * (m + n) > 100 ? 20 * (m + n) : 100) : max_pivots;
-    if (block_size <= 0) block_size = m < 1000 ? m / 4 : (m < 10000 ? m / 8 : m / 16);  // simplex_adaptive.py:89-96
-    if (block_size < 1) block_size = 1;
-    c.block_size = rule == MCF_RULE_DEVEX_BLOCK ? block_size : (m > 0 ? m : 1);
-    c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
-    if (c.num_blocks < 1) c.num_blocks = 1;
+    init_blocks(e, block_size);
     const auto t0 = std::chrono::steady_clock::now();
     int64_t ntrace = 0;
     while (c.status == MCF_RUNNING) {
-        int64_t lo = 0, hi = m;
-        if (rule == MCF_RULE_DEVEX_BLOCK) { lo = c.block_start; hi = lo + c.block_size < m ? lo + c.block_size : m; }
         int64_t key, arc;
-        price(e, lo, hi, &key, &arc);
-        c.arcs_priced += hi - lo;
-        if (trace_arcs && ntrace < trace_cap) trace_arcs[ntrace++] = arc;
+        const int64_t priced = price(e, 0, 1, &key, &arc);
+        if (c.pivots < c.max_pivots) c.arcs_priced += priced;
+        if (trace_arcs && ntrace < trace_cap) trace_arcs[ntrace++] = arc < 0 ? -1 : (arc >> 32);
         mcf_pivot_seq(e.view, key, arc, rule);
         if (c.apply) {
             // the two ranges the apply kernel covers: this pivot's and the stale one
@@ -122,18 +139,22 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     *status = r.status;
     objective_hi_lo[0] = (int64_t)(r.objective >> 64);
     objective_hi_lo[1] = (int64_t)(uint64_t)r.objective;
-    for (int64_t i = 0; i < m; ++i) {
-        if (flow) flow[i] = e.im.arcw[i].flow;
-        if (in_tree) in_tree[i] = e.im.state[i] == 0;
+    for (int64_t i = 0; i < m; ++i) {  // engine order -> caller's order
+        if (flow) flow[e.im.orig[i]] = e.im.arcw[i].flow;
+        if (in_tree) in_tree[e.im.orig[i]] = e.im.state[i] == 0;
     }
     if (potential) for (int32_t v = 0; v < n; ++v) potential[v] = e.im.pi[v] - e.im.pi[n];
     stats[0] = c.pivots; stats[1] = c.degenerate; stats[2] = c.bound_flips; stats[3] = c.arcs_priced;
-    stats[4] = c.nodes_moved; stats[5] = c.subtree_nodes; stats[6] = c.cycle_arcs; stats[7] = c.unbounded_arc;
+    stats[4] = c.nodes_moved; stats[5] = c.subtree_nodes; stats[6] = c.cycle_arcs;
+    stats[7] = c.unbounded_arc >= 0 ? e.im.orig[c.unbounded_arc] : -1;
     stats[8] = r.artificial_flow; stats[9] = (int64_t)(secs * 1e9);
     const int32_t* ord = e.view.order[c.cur];
     for (int32_t v = 0; v <= n; ++v) {
         if (parent) parent[v] = e.im.node[v].parent;
-        if (pred_arc) pred_arc[v] = e.im.node[v].pred < 0 ? -1 : e.im.node[v].pred >> 1;
+        if (pred_arc) {
+            const int64_t a = e.im.node[v].pred < 0 ? -1 : e.im.node[v].pred >> 1;
+            pred_arc[v] = a < 0 ? -1 : (a < m ? e.im.orig[a] : (int32_t)a);  // artificial arcs keep m + node
+        }
         if (size) size[v] = e.im.node[v].size;
         if (pos) pos[v] = e.im.node[v].pos;
         if (order) order[v] = ord[v];
@@ -145,35 +166,24 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
 // ---- step-wise API: lets the multi-process (gloo) tests drive one replica per rank exactly
 // the way the HIP engine is driven per pivot (price shard -> all-gather -> pivot).
 void* emul_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, const int64_t* cost,
-                  const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size) {
+                  const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int32_t bucketed) {
     Emul* e = new Emul();
     e->rule = rule;
     int err = 0;
-    std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e->im, &err);
+    std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e->im, &err, bucketed != 0);
     if (err) { std::fprintf(stderr, "emul_create: %s\n", msg.c_str()); delete e; return nullptr; }
     bind(*e);
     McfCtx& c = e->ctx;
     c.max_pivots = INT64_MAX;
-    if (block_size <= 0) block_size = m < 1000 ? m / 4 : (m < 10000 ? m / 8 : m / 16);
-    if (block_size < 1) block_size = 1;
-    c.block_size = rule == MCF_RULE_DEVEX_BLOCK ? block_size : (m > 0 ? m : 1);
-    c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
-    if (c.num_blocks < 1) c.num_blocks = 1;
+    init_blocks(*e, block_size);
     return e;
 }
 
-// best candidate of arcs [lo, hi) (intersected with the current Devex block)
-void emul_price(void* h, int64_t lo, int64_t hi, int64_t* key_arc /*[2]*/) {
+// best candidate of shard `r` of `G` (and of the current Devex block)
+void emul_price(void* h, int64_t r, int64_t G, int64_t* key_arc /*[2]*/) {
     Emul* e = static_cast<Emul*>(h);
-    const McfCtx& c = e->ctx;
-    if (e->rule == MCF_RULE_DEVEX_BLOCK) {
-        const int64_t bs = c.block_start, be = bs + c.block_size;
-        lo = lo > bs ? lo : bs;
-        hi = hi < be ? hi : be;
-    }
-    if (hi > e->im.m) hi = e->im.m;
     key_arc[0] = 0; key_arc[1] = -1;
-    if (c.status == MCF_RUNNING && lo < hi) price(*e, lo, hi, &key_arc[0], &key_arc[1]);
+    if (e->ctx.status == MCF_RUNNING) price(*e, r, G, &key_arc[0], &key_arc[1]);
 }
 
 // apply the best of `ncand` (key, arc) candidates, like k_pivot + k_apply
@@ -206,7 +216,7 @@ void emul_poll(void* h, int32_t* status, int64_t* pivots, int64_t* objective_hi_
     *status = e->ctx.status == MCF_RUNNING ? -1 : r.status;
     *pivots = e->ctx.pivots;
     if (objective_hi_lo) { objective_hi_lo[0] = (int64_t)(r.objective >> 64); objective_hi_lo[1] = (int64_t)(uint64_t)r.objective; }
-    if (flow) for (int64_t i = 0; i < e->im.m; ++i) flow[i] = e->im.arcw[i].flow;
+    if (flow) for (int64_t i = 0; i < e->im.m; ++i) flow[e->im.orig[i]] = e->im.arcw[i].flow;
 }
 
 void emul_destroy(void* h) { delete static_cast<Emul*>(h); }

@@ -15,14 +15,15 @@ from conftest import ROOT, load_synthetic
 from network_flow_solver_amd import distributed
 
 
-def test_shard_bounds_tile_the_arc_list():
-    for m in (0, 1, 5, 2048, 2049, 16_777_216):
+def test_shard_slices_tile_every_bucket():
+    for off in ([0, 0, 0, 0, 0, 0, 0, 0, 0], [0, 3, 3, 10, 40, 41, 100, 2048, 2049], list(range(0, 9 * 2_000_001, 2_000_001))):
         for world in (1, 2, 3, 8):
-            cuts = [distributed.shard_bounds(m, world, r) for r in range(world)]
-            assert cuts[0][0] == 0 and cuts[-1][1] == m
-            for (lo, hi), (lo2, _) in zip(cuts, cuts[1:]):
-                assert hi == lo2 and lo <= hi
-            assert all(lo % 4 == 0 for lo, _ in cuts)
+            per_rank = [distributed.shard_slices(off, world, r) for r in range(world)]
+            for x in range(8):
+                cuts = [per_rank[r][x] for r in range(world)]
+                assert cuts[0][0] == off[x] and cuts[-1][1] == off[x + 1]
+                for (lo, hi), (lo2, _) in zip(cuts, cuts[1:]):
+                    assert hi == lo2 and lo <= hi
 
 
 class EmulShardEngine:
@@ -34,7 +35,7 @@ class EmulShardEngine:
         import oracle
 
         self.torch = torch
-        self.lo, self.hi = distributed.shard_bounds(inst.m, world, rank)
+        self.rank, self.world = rank, world
         self.st = oracle.EmulStepper(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
 
     def new_candidate_buffers(self, world):
@@ -42,7 +43,7 @@ class EmulShardEngine:
         return t.zeros(2, dtype=t.int64), t.zeros(2 * world, dtype=t.int64)
 
     def price_local(self, out):
-        self.st.price(self.lo, self.hi, out.numpy())
+        self.st.price(self.rank, self.world, out.numpy())
 
     def pivot(self, cands, ncand):
         self.st.pivot(cands.numpy(), ncand)
