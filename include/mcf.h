@@ -77,7 +77,7 @@ typedef struct mcf_options {
     int64_t shard_rank;      /* multi-GPU: this handle prices shard shard_rank of shard_count */
     int64_t shard_count;     /*   (0 or 1 = all arcs); a shard is 1/shard_count of every XCD head bucket */
     int32_t price_blocks;    /* pricing grid size; 0 = auto */
-    int32_t reserved;
+    int32_t no_fused;        /* 1 = never use the fused LDS-resident kernel for small instances */
 } mcf_options;
 
 typedef struct mcf_stats {

@@ -105,6 +105,15 @@ struct McfCtx {
     int32_t t2_old, t2_new, t2_size;  // old start a, new start b, |T2|
     int32_t nseg;              // entries in seg[] (sorted by dst, cover [t2_new, t2_new+t2_size))
     int64_t sigma;             // potential shift of the moved subtree
+    // ---- hand-over from mcf_pivot_walk (one lane) to mcf_pivot_finish (all lanes)
+    int32_t stage;             // 0 = nothing to finish, 1 = bound flip, 2 = basis swap
+    int32_t pv_e, pv_s;        // entering arc (engine index), its state
+    int32_t pv_n1, pv_n2;      // recorded path lengths (first / second side)
+    int32_t pv_result, pv_k;   // blocking side (1 / 2), stem index of q on that side
+    int32_t pv_vin, pv_leave;  // new parent of the re-hung subtree, leaving arc
+    int32_t pv_leave_state;    // state the leaving arc takes (+1 ends at 0 flow, -1 at capacity)
+    int32_t pv_tail_in_t2;
+    int64_t pv_delta;
 };
 
 // Raw views the core functions operate on (device pointers in the kernels,
@@ -125,6 +134,8 @@ struct McfView {
     int32_t* order[2];      // [n_nodes] each
     int32_t* path1;         // [n_nodes] scratch: nodes on the `first` side of the cycle
     int32_t* path2;         // [n_nodes] scratch: nodes on the `second` side
+    McfNode* rec1;          // [n_nodes] scratch: their node records as read during the walk
+    McfNode* rec2;          // [n_nodes]
     McfSeg* seg;            // [2*n_nodes + 2] scratch
     McfCtx* ctx;
 };
@@ -158,17 +169,21 @@ MCF_HD int64_t mcf_violation(const McfView& v, int64_t i) {
 }
 
 // ---------------------------------------------------------------------------
-// The sequential part of one pivot: executed by ONE thread.
+// One pivot = mcf_pivot_walk (ONE lane) + mcf_pivot_finish (ALL lanes of the workgroup,
+// after a barrier).
 //
-// Input: the winning candidate (already reduced over blocks / ranks).
-// Work:  O(cycle length) dependent loads -- join search by subtree size, ratio
-//        test with the strongly-feasible tie rule, flow augmentation, state
-//        swap, re-parenting of the stem, subtree-size bookkeeping, and the
-//        descriptor (segments, ranges, sigma) for the data-parallel apply pass.
+// walk:   the only inherently sequential piece -- O(cycle length) dependent loads: join
+//         search by subtree size, ratio test with the strongly-feasible tie rule.  It records
+//         the path nodes and their records, takes every scalar decision, and leaves a
+//         descriptor in the control block (stage / pv_* and the apply descriptor).
+// finish: everything that touches arrays -- flow augmentation, state swap, subtree-size
+//         bookkeeping, stem re-parenting, the segments of the block permutation.  Each path
+//         element has a closed form from the recorded records, so lanes just stride over them.
 // ---------------------------------------------------------------------------
-MCF_HD void mcf_pivot_seq(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
+MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
     McfCtx* c = v.ctx;
     c->apply = 0;
+    c->stage = 0;
     if (c->pending_flip) {  // the previous apply pass wrote order[cur ^ 1]
         c->cur ^= 1;
         c->prev_lo = c->lo;
@@ -206,85 +221,76 @@ MCF_HD void mcf_pivot_seq(const McfView& v, int64_t best_key, int64_t best_arc, 
     int32_t u = first, w = second;
     McfNode ru = v.node[u], rw = v.node[w];
     int64_t d1 = MCF_INF, d2 = MCF_INF;
-    int32_t q1 = -1, q2 = -1, n1 = 0, n2 = 0;
+    int32_t k1 = -1, k2 = -1, n1 = 0, n2 = 0, ls1 = 1, ls2 = 1;
     while (u != w) {
         if (ru.size < rw.size) {
+            // the parent's record is the dependent chain: issue its load before the arc's
+            const McfNode nxt = v.node[ru.parent];
             const McfArcW a = v.arcw[ru.pred >> 1];
             // first side is walked against the flow: an up arc loses flow, a down arc gains
             const int64_t r = (ru.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
-            if (r < d1) { d1 = r; q1 = u; }
-            v.path1[n1++] = u;
+            if (r < d1) { d1 = r; k1 = n1; ls1 = (ru.pred & 1) ? 1 : -1; }
+            v.path1[n1] = u;
+            v.rec1[n1] = ru;
+            ++n1;
             u = ru.parent;
-            ru = v.node[u];
+            ru = nxt;
         } else {
+            const McfNode nxt = v.node[rw.parent];
             const McfArcW a = v.arcw[rw.pred >> 1];
             const int64_t r = (rw.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
-            if (r <= d2) { d2 = r; q2 = w; }
-            v.path2[n2++] = w;
+            if (r <= d2) { d2 = r; k2 = n2; ls2 = (rw.pred & 1) ? -1 : 1; }
+            v.path2[n2] = w;
+            v.rec2[n2] = rw;
+            ++n2;
             w = rw.parent;
-            rw = v.node[w];
+            rw = nxt;
         }
     }
-    const McfArcW ae = v.arcw[e];
-    const int64_t de = ae.cap;  // residual of the entering arc in its push direction
-    int32_t result, q;
+    const int64_t de = v.arcw[e].cap;  // residual of the entering arc in its push direction
+    int32_t result;
     int64_t delta;
-    if (d2 <= de && d2 <= d1) { result = 2; delta = d2; q = q2; }
-    else if (de <= d1) { result = 0; delta = de; q = -1; }
-    else { result = 1; delta = d1; q = q1; }
+    if (d2 <= de && d2 <= d1) { result = 2; delta = d2; }
+    else if (de <= d1) { result = 0; delta = de; }
+    else { result = 1; delta = d1; }
 
     if (delta >= MCF_INF) {  // simplex.py:1231-1246
         c->status = MCF_UNBOUNDED;
         c->unbounded_arc = e;
         return;
     }
-
-    // --- flow update along the cycle (simplex.py:1255-1283)
-    if (delta > 0) {
-        v.arcw[e].flow = ae.flow + (int64_t)s * delta;
-        for (int32_t k = 0; k < n1; ++k) {
-            const int32_t p = v.node[v.path1[k]].pred;
-            v.arcw[p >> 1].flow += (p & 1) ? -delta : delta;
-        }
-        for (int32_t k = 0; k < n2; ++k) {
-            const int32_t p = v.node[v.path2[k]].pred;
-            v.arcw[p >> 1].flow += (p & 1) ? delta : -delta;
-        }
-    } else {
-        c->degenerate += 1;
-    }
+    if (delta == 0) c->degenerate += 1;
     c->pivots += 1;
     c->cycle_arcs += n1 + n2 + 1;
+    c->pv_e = e; c->pv_s = s; c->pv_n1 = n1; c->pv_n2 = n2; c->pv_delta = delta; c->pv_result = result;
     if (v.weight) {  // Devex: only the selected arc's weight is refreshed (simplex_pricing.py:271-292);
         // ||B^-1 a||^2 of a tree basis = number of tree arcs between the end points
         const int32_t len = n1 + n2;
         v.weight[e] = (float)(len > 0 ? len : 1);
     }
-
     if (result == 0) {  // entering arc is also the leaving arc (simplex.py:1320-1334)
-        v.state[e] = (int8_t)(-s);
         c->bound_flips += 1;
+        c->stage = 1;
         return;
     }
 
-    // --- basis swap (simplex.py:1335-1425), tree part only
-    const int32_t* stem = result == 1 ? v.path1 : v.path2;   // stem[0] = u_in ... stem[k] = q
-    const int32_t nstem_side = result == 1 ? n1 : n2;
-    const int32_t* other = result == 1 ? v.path2 : v.path1;  // other[0] = v_in ... (join excluded)
-    const int32_t nother = result == 1 ? n2 : n1;
+    // --- basis swap (simplex.py:1335-1425): scalar decisions only
+    const int32_t k = result == 1 ? k1 : k2;                 // stem[0] = u_in ... stem[k] = q
+    const McfNode* srec = result == 1 ? v.rec1 : v.rec2;
     const int32_t v_in = result == 1 ? second : first;
-    const int32_t leave = v.node[q].pred >> 1;
-    v.state[e] = 0;
-    if (leave < v.m) v.state[leave] = v.arcw[leave].flow == 0 ? (int8_t)1 : (int8_t)-1;
-
-    // potential shift that zeroes the entering arc's reduced cost
+    const McfNode rq = srec[k];
     const bool tail_in_t2 = (result == 1) == (s > 0);
-    c->sigma = tail_in_t2 ? -rc : rc;
+    c->pv_k = k;
+    c->pv_vin = v_in;
+    c->pv_leave = rq.pred >> 1;
+    c->pv_leave_state = result == 1 ? ls1 : ls2;
+    c->pv_tail_in_t2 = tail_in_t2 ? 1 : 0;
+    c->sigma = tail_in_t2 ? -rc : rc;  // potential shift that zeroes the entering arc's reduced cost
 
-    const McfNode rq = v.node[q];
     const int32_t S = rq.size, a0 = rq.pos;
-    const McfNode rvin = v.node[v_in];
-
+    // v_in's record: the first element of the other side, or the join itself when that side is empty
+    const int32_t nother = result == 1 ? n2 : n1;
+    const McfNode rvin = nother > 0 ? (result == 1 ? v.rec2[0] : v.rec1[0]) : ru;  // ru == rw == join record
     // insertion point in OLD coordinates: directly behind v_in, or at the end of
     // v_in's block -- whichever moves fewer array elements
     const int32_t tA = rvin.pos + 1, tB = rvin.pos + rvin.size;
@@ -297,63 +303,86 @@ MCF_HD void mcf_pivot_seq(const McfView& v, int64_t best_key, int64_t best_arc, 
     c->t2_size = S;
     c->lo = t < a0 ? t : a0;
     c->hi = t > a0 + S ? t : a0 + S;
-
-    // subtree sizes outside T2: the old ancestors of q lose S, v_in and its ancestors gain S
-    // (join and above keep their size)
-    int32_t k = 0;
-    while (stem[k] != q) ++k;
-    for (int32_t i = k + 1; i < nstem_side; ++i) v.node[stem[i]].size -= S;
-    for (int32_t i = 0; i < nother; ++i) v.node[other[i]].size += S;
-
-    // re-root T2 at u_in: reverse the stem, and emit the block permutation.
-    // Old layout: block(s_i) = [p_i, p_i + z_i), nested, s_k = q.
-    // New layout: block(s_0), then for i = 1..k: s_i + what precedes block(s_{i-1}) inside
-    // block(s_i), then what follows it.
-    int32_t nseg = 0;
-    int32_t prev_node = v_in, prev_pred = (e << 1) | (tail_in_t2 ? 1 : 0);
-    int32_t p_prev = 0, z_prev = 0, out = b;
-    for (int32_t i = 0; i <= k; ++i) {
-        const int32_t sn = stem[i];
-        const McfNode r = v.node[sn];
-        McfNode nr;
-        nr.parent = prev_node;
-        nr.pred = prev_pred;
-        nr.pos = r.pos;  // rewritten by the apply pass
-        if (i == 0) {
-            nr.size = S;
-            v.seg[nseg++] = McfSeg{out, r.pos, r.size};
-            out += r.size;
-        } else {
-            nr.size = S - z_prev;  // all of T2 except what stays below s_{i-1}
-            const int32_t left = p_prev - r.pos;                            // s_i itself + blocks before block(s_{i-1})
-            const int32_t right = (r.pos + r.size) - (p_prev + z_prev);    // blocks after it
-            v.seg[nseg++] = McfSeg{out, r.pos, left};
-            out += left;
-            if (right > 0) {
-                v.seg[nseg++] = McfSeg{out, p_prev + z_prev, right};
-                out += right;
-            }
-        }
-        // the arc s_i used to hang on now carries s_{i+1}; its direction bit flips
-        prev_pred = r.pred ^ 1;
-        prev_node = sn;
-        p_prev = r.pos;
-        z_prev = r.size;
-        v.node[sn] = nr;
-    }
-    c->nseg = nseg;
+    c->nseg = 2 * k + 1;
     c->apply = 1;
     c->pending_flip = 1;
     c->subtree_nodes += S;
     c->nodes_moved += c->hi - c->lo;
-    if (out != b + S) c->status = MCF_INTERNAL_ERROR;
-#if defined(MCF_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
-    if (out != b + S) {
-        fprintf(stderr, "pivot %lld: e=%d s=%d result=%d q=%d S=%d a0=%d t=%d b=%d out=%d k=%d n1=%d n2=%d v_in=%d\n",
-                (long long)c->pivots, e, s, result, q, S, a0, t, b, out, k, n1, n2, v_in);
-        for (int32_t i = 0; i < nseg; ++i) fprintf(stderr, "  seg dst=%d src=%d len=%d\n", v.seg[i].dst, v.seg[i].src, v.seg[i].len);
+    c->stage = 2;
+}
+
+MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
+    const McfCtx* c = v.ctx;
+    const int32_t stage = c->stage;
+    if (stage == 0) return;
+    const int32_t e = c->pv_e, s = c->pv_s, n1 = c->pv_n1, n2 = c->pv_n2;
+    const int64_t delta = c->pv_delta;
+
+    // --- flow update along the cycle (simplex.py:1255-1283): distinct arcs, one per lane
+    if (delta > 0) {
+        for (int32_t i = lane; i < n1 + n2; i += nlanes) {
+            const bool side1 = i < n1;
+            const int32_t p = side1 ? v.rec1[i].pred : v.rec2[i - n1].pred;
+            const bool up = (p & 1) != 0;
+            // first side is walked against the flow, second side with it
+            v.arcw[p >> 1].flow += (side1 == up) ? -delta : delta;
+        }
+        if (lane == 0) v.arcw[e].flow += (int64_t)s * delta;
     }
-#endif
+    if (stage == 1) {
+        if (lane == 0) v.state[e] = (int8_t)(-s);
+        return;
+    }
+
+    const int32_t result = c->pv_result, k = c->pv_k, v_in = c->pv_vin;
+    const int32_t* stem = result == 1 ? v.path1 : v.path2;
+    const McfNode* srec = result == 1 ? v.rec1 : v.rec2;
+    const int32_t nstem_side = result == 1 ? n1 : n2;
+    const int32_t* other = result == 1 ? v.path2 : v.path1;
+    const McfNode* orec = result == 1 ? v.rec2 : v.rec1;
+    const int32_t nother = result == 1 ? n2 : n1;
+    const int32_t S = c->t2_size, b = c->t2_new;
+    if (lane == 0) {
+        v.state[e] = 0;
+        if (c->pv_leave < v.m) v.state[c->pv_leave] = (int8_t)c->pv_leave_state;
+    }
+    // subtree sizes outside T2: the old ancestors of q lose S, v_in and its ancestors gain S
+    // (join and above keep their size)
+    for (int32_t i = k + 1 + lane; i < nstem_side; i += nlanes) v.node[stem[i]].size = srec[i].size - S;
+    for (int32_t i = lane; i < nother; i += nlanes) v.node[other[i]].size = orec[i].size + S;
+
+    // re-root T2 at u_in: reverse the stem and emit the block permutation.
+    // Old layout: block(s_i) = [p_i, p_i + z_i), nested, s_k = q.  New layout: block(s_0), then
+    // for i = 1..k: s_i + what precedes block(s_{i-1}) inside block(s_i), then what follows it;
+    // piece i starts at b + z_{i-1} because pieces 0..i-1 are exactly old block(s_{i-1}).
+    for (int32_t i = lane; i <= k; i += nlanes) {
+        const McfNode r = srec[i];
+        McfNode nr;
+        nr.pos = r.pos;  // rewritten by the apply pass
+        if (i == 0) {
+            nr.parent = v_in;
+            nr.pred = (e << 1) | c->pv_tail_in_t2;
+            nr.size = S;
+            v.seg[0] = McfSeg{b, r.pos, r.size};
+        } else {
+            const McfNode rp = srec[i - 1];
+            nr.parent = stem[i - 1];
+            nr.pred = rp.pred ^ 1;  // the arc s_{i-1} used to hang on now carries s_i: direction bit flips
+            nr.size = S - rp.size;  // all of T2 except what stays below s_{i-1}
+            const int32_t left = rp.pos - r.pos;                            // s_i itself + blocks before block(s_{i-1})
+            const int32_t right = (r.pos + r.size) - (rp.pos + rp.size);   // blocks after it (may be empty)
+            const int32_t dst = b + rp.size;
+            v.seg[2 * i - 1] = McfSeg{dst, r.pos, left};
+            v.seg[2 * i] = McfSeg{dst + left, rp.pos + rp.size, right};
+        }
+        v.node[stem[i]] = nr;
+    }
+}
+
+// Convenience for single-threaded callers (CPU emulation): the whole pivot.
+MCF_HD void mcf_pivot_seq(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
+    mcf_pivot_walk(v, best_key, best_arc, rule);
+    mcf_pivot_finish(v, 0, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -378,8 +407,10 @@ MCF_HD int32_t mcf_apply_source(const McfCtx& c, const McfSeg* seg, int32_t j, b
 
 // One element of the apply pass (the HIP kernel runs this for a grid-strided j).
 MCF_HD void mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
-    const int32_t* src = v.order[c.cur];
-    int32_t* dst = v.order[c.cur ^ 1];
+    // selects, not a runtime-indexed member array: a view held in registers must not be
+    // forced into private memory
+    const int32_t* src = c.cur ? v.order[1] : v.order[0];
+    int32_t* dst = c.cur ? v.order[0] : v.order[1];
     if (j >= c.lo && j < c.hi) {
         bool in_t2;
         const int32_t i = mcf_apply_source(c, v.seg, j, &in_t2);

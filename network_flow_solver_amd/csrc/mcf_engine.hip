@@ -8,8 +8,9 @@
 //             HBM-bound: 13 B/arc (+4 B/arc Devex weight) + 8 B per distinct node.
 //             Replaces simplex.py:498-617 and simplex_pricing.py:97-137, 310-357.
 //   k_pivot   one workgroup: final arg-max over the workgroup candidates (or the candidates
-//             all-gathered from the other ranks), then ONE lane runs mcf_pivot_seq (join,
-//             ratio test, flow update, stem re-parenting; O(cycle) dependent loads).
+//             all-gathered from the other ranks), then ONE lane runs mcf_pivot_walk (join +
+//             ratio test: O(cycle) dependent loads) and ALL lanes mcf_pivot_finish (flow update,
+//             stem re-parenting, segment table: one path element per lane).
 //             Replaces basis.py:178-241 and simplex.py:1198-1425.
 //   k_apply   grid-wide block permutation of the preorder array for the re-hung subtree +
 //             its potential shift (pi += sigma) + pos rewrite.  Replaces the per-pivot
@@ -48,16 +49,35 @@ constexpr int kUnroll = MCF_PRICE_UNROLL;  // 4-arc groups in flight per lane in
 thread_local std::string g_create_error;
 
 // ------------------------------------------------------------------ device helpers
-__device__ __forceinline__ void wave_argmax(int64_t& key, int64_t& arc) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int64_t ok = (int64_t)__shfl_xor((long long)key, off, 64);
-        const int64_t oa = (int64_t)__shfl_xor((long long)arc, off, 64);
-        if (mcf_cand_better(ok, oa, key, arc)) { key = ok; arc = oa; }
-    }
+// Wave-wide arg-max of (key, id): max-reduce the 64-bit key with xor shuffles, then resolve the
+// id among the lanes that hold the maximum with a ballot + scalar readlanes (almost always one
+// lane), instead of shuffling both words through every step.  Result is wave-uniform.
+__device__ __forceinline__ int64_t readlane64(int64_t x, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), lane);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-// Block-wide arg-max; result valid in thread 0.
+__device__ __forceinline__ void wave_argmax(int64_t& key, int64_t& arc) {
+    int64_t mx = key;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int64_t o = (int64_t)__shfl_xor((long long)mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    uint64_t mask = __ballot(key == mx && key > 0);
+    int64_t best = -1;
+    while (mask) {  // uniform loop: one iteration unless several lanes tie on the key
+        const int lane = __ffsll((unsigned long long)mask) - 1;
+        const int64_t a = readlane64(arc, lane);
+        if (best < 0 || a < best) best = a;
+        mask &= mask - 1;
+    }
+    key = best < 0 ? 0 : mx;
+    arc = best;
+}
+
+// Block-wide arg-max; result valid in thread 0 (and in all of wave 0).
 template <int THREADS>
 __device__ __forceinline__ void block_argmax(int64_t& key, int64_t& arc) {
     __shared__ int64_t s_key[THREADS / 64];
@@ -66,10 +86,11 @@ __device__ __forceinline__ void block_argmax(int64_t& key, int64_t& arc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { s_key[wave] = key; s_arc[wave] = arc; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < THREADS / 64; ++w)
-            if (mcf_cand_better(s_key[w], s_arc[w], key, arc)) { key = s_key[w]; arc = s_arc[w]; }
+    if (wave == 0) {
+        const bool has = lane < THREADS / 64;
+        key = has ? s_key[has ? lane : 0] : 0;
+        arc = has ? s_arc[has ? lane : 0] : -1;
+        wave_argmax(key, arc);
     }
 }
 
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(kPivotThreads) void k_reduce(const McfCand* __restr
 
 // ------------------------------------------------------------------ k_pivot
 __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView v, const McfCand* __restrict__ cand, int ncand,
-                                                          int32_t rule, int64_t priced_per_pass) {
+                                                          int32_t rule) {
     if (v.ctx->status != MCF_RUNNING) {
         if (threadIdx.x == 0) v.ctx->apply = 0;
         return;
@@ -189,9 +210,24 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView v, const McfCan
     }
     block_argmax<kPivotThreads>(key, arc);
     if (threadIdx.x == 0) {
-        if (v.ctx->pivots < v.ctx->max_pivots) v.ctx->arcs_priced += priced_per_pass;
-        mcf_pivot_seq(v, key, arc, rule);
+        McfCtx* c = v.ctx;
+        if (c->pivots < c->max_pivots) {
+            // whole-job accounting: the arcs of this pass over ALL shards
+            int64_t priced = v.m;  // full sweep: every arc (no 64-bit divisions on the hot path)
+            if (rule == MCF_RULE_DEVEX_BLOCK && c->num_blocks > 1) {
+                priced = 0;
+                for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+                    int64_t lo, hi;
+                    mcf_bucket_slice(v.bucket_off, x, 0, 1, c->block_index, c->num_blocks, &lo, &hi);
+                    priced += hi - lo;
+                }
+            }
+            c->arcs_priced += priced;
+        }
+        mcf_pivot_walk(v, key, arc, rule);   // sequential: O(cycle) dependent loads
     }
+    __syncthreads();
+    mcf_pivot_finish(v, threadIdx.x, kPivotThreads);  // array updates, one path element per lane
 }
 
 // ------------------------------------------------------------------ k_apply
@@ -204,6 +240,170 @@ __global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
     // catch-up copy of what the previous apply changed in the other buffer
     for (int64_t j = c.prev_lo + tid; j < c.prev_hi; j += stride)
         if (j < c.lo || j >= c.hi) mcf_apply_one(v, c, (int32_t)j);
+}
+
+// ------------------------------------------------------------------ k_solve_small: fused LDS-resident pivot loop
+// Instances whose whole state fits in one CU's 160 KiB of LDS (netgen_8_08a: ~96 KiB) are
+// latency-bound, not bandwidth-bound: 27 KB per sweep is nothing, three kernel boundaries and
+// a dozen dependent global loads per pivot are everything.  This kernel copies the instance
+// into LDS once, runs pivots back to back in ONE persistent workgroup (price: all 1024 lanes
+// over LDS; pivot: the same mcf_pivot_walk / mcf_pivot_finish; apply: all lanes through the same
+// mcf_apply_one) and copies the state back.  Same arc sets, same tie rule, same core functions
+// as the three-kernel path, so the pivot sequence is identical.
+struct SmallLayout {
+    uint32_t tail, head, cost, orig, state, weight, arcw, pi, node, order0, order1, path1, path2, rec1, rec2, seg, ctx, total;
+};
+
+constexpr int kSmallThreads = 1024;
+
+__device__ __forceinline__ void copy_words(void* dst, const void* src, uint32_t bytes) {
+    const uint32_t n = bytes >> 2;
+    const int32_t* s = static_cast<const int32_t*>(src);
+    int32_t* d = static_cast<int32_t*>(dst);
+    for (uint32_t i = threadIdx.x; i < n; i += kSmallThreads) d[i] = s[i];
+}
+
+#ifdef MCF_STAMPS
+#define STAMP(slot)                                                                       \
+    do {                                                                                  \
+        if (threadIdx.x == 0) {                                                           \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                 \
+            stamps_[slot] += now_ - last_;                                                \
+            last_ = now_;                                                                 \
+        }                                                                                 \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallLayout L, int32_t rule) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef MCF_STAMPS
+    unsigned long long stamps_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+    const uint32_t m_pad4 = (uint32_t)((g.m + 1023) / 1024 * 1024) * 4u;
+    const uint32_t m_padb = m_pad4 >> 2;
+    const uint32_t N = (uint32_t)g.n_nodes;
+    const uint32_t arcw_b = (uint32_t)(g.m + N - 1) * 16u;
+    McfView v = g;
+    v.tail = reinterpret_cast<const int32_t*>(smem + L.tail);
+    v.head = reinterpret_cast<const int32_t*>(smem + L.head);
+    v.cost = reinterpret_cast<const int32_t*>(smem + L.cost);
+    v.orig = reinterpret_cast<const int32_t*>(smem + L.orig);
+    v.state = reinterpret_cast<int8_t*>(smem + L.state);
+    v.weight = g.weight ? reinterpret_cast<float*>(smem + L.weight) : nullptr;
+    v.arcw = reinterpret_cast<McfArcW*>(smem + L.arcw);
+    v.pi = reinterpret_cast<int64_t*>(smem + L.pi);
+    v.node = reinterpret_cast<McfNode*>(smem + L.node);
+    v.order[0] = reinterpret_cast<int32_t*>(smem + L.order0);
+    v.order[1] = reinterpret_cast<int32_t*>(smem + L.order1);
+    v.path1 = reinterpret_cast<int32_t*>(smem + L.path1);
+    v.path2 = reinterpret_cast<int32_t*>(smem + L.path2);
+    v.rec1 = reinterpret_cast<McfNode*>(smem + L.rec1);
+    v.rec2 = reinterpret_cast<McfNode*>(smem + L.rec2);
+    v.seg = reinterpret_cast<McfSeg*>(smem + L.seg);
+    v.ctx = reinterpret_cast<McfCtx*>(smem + L.ctx);
+
+    copy_words(smem + L.tail, g.tail, m_pad4);
+    copy_words(smem + L.head, g.head, m_pad4);
+    copy_words(smem + L.cost, g.cost, m_pad4);
+    copy_words(smem + L.orig, g.orig, m_pad4);
+    copy_words(smem + L.state, g.state, m_padb);
+    if (g.weight) copy_words(smem + L.weight, g.weight, m_pad4);
+    copy_words(smem + L.arcw, g.arcw, arcw_b);
+    copy_words(smem + L.pi, g.pi, N * 8u);
+    copy_words(smem + L.node, g.node, N * 16u);
+    copy_words(smem + L.order0, g.order[0], N * 4u);
+    copy_words(smem + L.order1, g.order[1], N * 4u);
+    copy_words(smem + L.ctx, g.ctx, (uint32_t)sizeof(McfCtx));
+    __syncthreads();
+    STAMP(0);
+
+    McfCtx* c = v.ctx;
+    // per-bucket bounds of the block being priced, cached in LDS: mcf_bucket_slice costs four
+    // emulated 64-bit divisions, so it is re-evaluated (by 8 lanes) only when the block changes
+    __shared__ int64_t s_lo[MCF_NUM_BUCKETS], s_hi[MCF_NUM_BUCKETS];
+    __shared__ int64_t s_block;
+    if (threadIdx.x < MCF_NUM_BUCKETS) {
+        const int64_t nb0 = rule == MCF_RULE_DEVEX_BLOCK ? c->num_blocks : 1;
+        const int64_t kb0 = rule == MCF_RULE_DEVEX_BLOCK ? c->block_index : 0;
+        mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, kb0, nb0, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
+        if (threadIdx.x == 0) s_block = kb0;
+    }
+    __syncthreads();
+    while (c->status == MCF_RUNNING) {
+        // ---- price: the arc set of k_price for shard 0 of 1
+        int64_t key = 0, arc = -1;
+        {
+            // 128 lanes per head bucket, all eight buckets at once
+            constexpr int kPer = kSmallThreads / MCF_NUM_BUCKETS;
+            const int x = threadIdx.x / kPer, l = threadIdx.x % kPer;
+            const int64_t lo = s_lo[x], hi = s_hi[x];
+            for (int64_t i = lo + l; i < hi; i += kPer) {
+                if (!v.state[i]) continue;
+                const int64_t viol = mcf_violation(v, i);
+                if (viol <= 0) continue;
+                int64_t kk = viol;
+                if (rule == MCF_RULE_DEVEX_BLOCK) {
+                    const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
+                    kk = __double_as_longlong(merit);
+                }
+                const int64_t id = mcf_pack_arc(v.orig[i], i);
+                if (mcf_cand_better(kk, id, key, arc)) { key = kk; arc = id; }
+            }
+        }
+        STAMP(1);
+        block_argmax<kSmallThreads>(key, arc);
+        STAMP(2);
+        // ---- pivot: one lane, everything it touches is in LDS
+        if (threadIdx.x == 0) {
+            if (c->pivots < c->max_pivots) {
+                int64_t priced = 0;
+                for (int x = 0; x < MCF_NUM_BUCKETS; ++x) priced += s_hi[x] - s_lo[x];
+                c->arcs_priced += priced;
+            }
+            mcf_pivot_walk(v, key, arc, rule);
+        }
+        STAMP(3);
+        __syncthreads();
+        mcf_pivot_finish(v, threadIdx.x, kSmallThreads);
+        __syncthreads();
+        STAMP(4);
+        // ---- apply: block permutation of the preorder array + potential shift
+        if (c->status == MCF_RUNNING || c->apply) {
+            if (c->apply) {  // the descriptor stays in LDS (broadcast reads); a private copy would spill
+                const int32_t lo = c->lo, hi = c->hi, plo = c->prev_lo, phi = c->prev_hi;
+                for (int32_t j = lo + threadIdx.x; j < hi; j += kSmallThreads) mcf_apply_one(v, *c, j);
+                for (int32_t j = plo + threadIdx.x; j < phi; j += kSmallThreads)
+                    if (j < lo || j >= hi) mcf_apply_one(v, *c, j);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) c->apply = 0;
+        if (rule == MCF_RULE_DEVEX_BLOCK && threadIdx.x < MCF_NUM_BUCKETS && s_block != c->block_index)
+            mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, c->block_index, c->num_blocks, &s_lo[threadIdx.x],
+                             &s_hi[threadIdx.x]);
+        __syncthreads();
+        if (threadIdx.x == 0) s_block = c->block_index;
+        STAMP(5);
+    }
+
+    copy_words(g.state, smem + L.state, m_padb);
+    if (g.weight) copy_words(g.weight, smem + L.weight, m_pad4);
+    copy_words(g.arcw, smem + L.arcw, arcw_b);
+    copy_words(g.pi, smem + L.pi, N * 8u);
+    copy_words(g.node, smem + L.node, N * 16u);
+    copy_words(g.order[0], smem + L.order0, N * 4u);
+    copy_words(g.order[1], smem + L.order1, N * 4u);
+    copy_words(g.ctx, smem + L.ctx, (uint32_t)sizeof(McfCtx));
+#ifdef MCF_STAMPS
+    STAMP(6);
+    if (threadIdx.x == 0) {  // diagnostic build only: cycle sums into the (global) path scratch, read by mcf_debug_stamps
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(g.rec1);
+        for (int i = 0; i < 8; ++i) out[i] = stamps_[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ k_ctl: (re)arm the control block
@@ -233,6 +433,7 @@ struct mcf_handle {
     int64_t* d_pi = nullptr;
     McfNode* d_node = nullptr;
     int32_t *d_order0 = nullptr, *d_order1 = nullptr, *d_path1 = nullptr, *d_path2 = nullptr;
+    McfNode *d_rec1 = nullptr, *d_rec2 = nullptr;
     McfSeg* d_seg = nullptr;
     McfCtx* d_ctx = nullptr;
     McfCand* d_cand = nullptr;
@@ -242,6 +443,8 @@ struct mcf_handle {
     McfView view{};
     int price_blocks = 1;
     int apply_blocks = 1;
+    bool small = false;       // whole instance fits in LDS: fused single-workgroup pivot loop
+    SmallLayout small_layout{};
     int64_t shard = 0, shards = 1;
     int64_t shard_arcs = 0;  // arcs of this rank's shard (all buckets)
     int64_t priced_per_pass = 0;
@@ -332,8 +535,7 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
 void launch_pivot_triplet(mcf_handle* h, hipStream_t s) {
     const int32_t rule = h->opt.rule;
     launch_price(h, s, h->view, rule, rule == MCF_RULE_DEVEX_BLOCK);
-    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, h->d_cand, h->price_blocks, rule,
-                       h->priced_per_pass);
+    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, h->d_cand, h->price_blocks, rule);
     hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
 }
 
@@ -363,8 +565,7 @@ int run_batch_profiled(mcf_handle* h, int batch) {
         HIP_TRY(h, hipEventRecord(ev[0], h->stream));
         launch_price(h, h->stream, h->view, rule, rule == MCF_RULE_DEVEX_BLOCK);
         HIP_TRY(h, hipEventRecord(ev[1], h->stream));
-        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, h->stream, h->view, h->d_cand, h->price_blocks, rule,
-                           h->priced_per_pass);
+        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, h->stream, h->view, h->d_cand, h->price_blocks, rule);
         HIP_TRY(h, hipEventRecord(ev[2], h->stream));
         hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, h->stream, h->view);
         HIP_TRY(h, hipEventRecord(ev[3], h->stream));
@@ -394,7 +595,7 @@ void free_all(mcf_handle* h) {
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
-    (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_one);
+    (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_one);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
     if (h->h_one) (void)hipHostFree(h->h_one);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -486,6 +687,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     if ((e = dalloc(&h->d_order1, N)) != hipSuccess) return fail("hipMalloc order", e);
     if ((e = dalloc(&h->d_path1, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_path2, N)) != hipSuccess) return fail("hipMalloc path", e);
+    if ((e = dalloc(&h->d_rec1, N)) != hipSuccess) return fail("hipMalloc rec", e);
+    if ((e = dalloc(&h->d_rec2, N)) != hipSuccess) return fail("hipMalloc rec", e);
     if ((e = dalloc(&h->d_seg, 2 * N + 2)) != hipSuccess) return fail("hipMalloc seg", e);
     if ((e = dalloc(&h->d_ctx, 1)) != hipSuccess) return fail("hipMalloc ctx", e);
     if ((e = dalloc(&h->d_cand, kMaxPriceBlocks)) != hipSuccess) return fail("hipMalloc cand", e);
@@ -501,8 +704,29 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     v.weight = opt.rule == MCF_RULE_DEVEX_BLOCK ? h->d_weight : nullptr;
     v.arcw = h->d_arcw; v.pi = h->d_pi; v.node = h->d_node;
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
-    v.path1 = h->d_path1; v.path2 = h->d_path2; v.seg = h->d_seg; v.ctx = h->d_ctx;
+    v.path1 = h->d_path1; v.path2 = h->d_path2; v.rec1 = h->d_rec1; v.rec2 = h->d_rec2; v.seg = h->d_seg; v.ctx = h->d_ctx;
 
+    {
+        // LDS plan of the fused small-instance path (every offset a multiple of 16)
+        SmallLayout& L = h->small_layout;
+        uint32_t off = 0;
+        auto take = [&](uint64_t bytes) { const uint32_t o = off; off += (uint32_t)((bytes + 15) / 16 * 16); return o; };
+        const uint64_t mp = (uint64_t)im.m_pad, Nn = (uint64_t)im.n_nodes;
+        L.tail = take(mp * 4); L.head = take(mp * 4); L.cost = take(mp * 4); L.orig = take(mp * 4);
+        L.state = take(mp); L.weight = take(opt.rule == MCF_RULE_DEVEX_BLOCK ? mp * 4 : 0);
+        L.arcw = take((uint64_t)im.arcw.size() * 16); L.pi = take(Nn * 8); L.node = take(Nn * 16);
+        L.order0 = take(Nn * 4); L.order1 = take(Nn * 4); L.path1 = take(Nn * 4); L.path2 = take(Nn * 4);
+        L.rec1 = take(Nn * 16); L.rec2 = take(Nn * 16);
+        L.seg = take((2 * Nn + 2) * sizeof(McfSeg)); L.ctx = take(sizeof(McfCtx));
+        L.total = off;
+        const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 92 + 4096;
+        h->small = !opt.no_fused && !opt.profile && h->shards == 1 && need < 150 * 1024 && L.total <= 158 * 1024;
+        if (h->small) {
+            hipError_t fe = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+            if (fe != hipSuccess) h->small = false;  // fall back to the three-kernel GPU path
+        }
+    }
     const int rc = upload_image(h);
     if (rc != MCF_OK) { g_create_error = h->err; free_all(h); delete h; return rc; }
     *out = h;
@@ -538,7 +762,7 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
     const int64_t final_cap = start + max_pivots;
     if (cb_interval <= 0) cb_interval = 100;
     const int batch = h->opt.batch_pivots;
-    const bool graph = h->opt.use_graph && !h->opt.profile;
+    const bool graph = h->opt.use_graph && !h->opt.profile && !h->small;
     if (graph) { rc = build_graph(h, batch); if (rc) return rc; }
     bool stop = false;
     while (!stop) {
@@ -552,7 +776,10 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
         hipLaunchKernelGGL(k_ctl, dim3(1), dim3(1), 0, h->stream, h->d_ctx, cap, 1);
         // pivot until the device reports something other than "still running"
         for (;;) {
-            if (h->opt.profile) { rc = run_batch_profiled(h, batch); if (rc) return rc; }
+            if (h->small)
+                hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(kSmallThreads), h->small_layout.total, h->stream, h->view,
+                                   h->small_layout, h->opt.rule);
+            else if (h->opt.profile) { rc = run_batch_profiled(h, batch); if (rc) return rc; }
             else if (graph) HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
             else for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream);
             HIP_TRY(h, hipGetLastError());
@@ -694,11 +921,8 @@ int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev) {
 int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int32_t ncand) {
     if (!h || !cands_dev || ncand < 1) return MCF_E_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // every rank accounts the arcs of ALL shards, so arcs_priced is the whole-job figure
-    const int64_t nblk = h->h_ctx->num_blocks > 0 ? h->h_ctx->num_blocks : 1;
-    const int64_t priced = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? (h->im.m + nblk - 1) / nblk : h->im.m;
     hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, reinterpret_cast<const McfCand*>(cands_dev), ncand,
-                       h->opt.rule, priced);
+                       h->opt.rule);
     hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
     HIP_TRY(h, hipGetLastError());
     return MCF_OK;
@@ -804,6 +1028,13 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
     if (potential_with_root) HIP_TRY(h, hipMemcpy(potential_with_root, h->d_pi, (size_t)im.n_nodes * 8, hipMemcpyDeviceToHost));
     return MCF_OK;
 }
+
+#ifdef MCF_STAMPS
+int mcf_debug_stamps(mcf_handle* h, unsigned long long* out8) {
+    HIP_TRY(h, hipMemcpy(out8, h->d_rec1, 64, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
+#endif
 
 void mcf_destroy(mcf_handle* h) {
     if (!h) return;

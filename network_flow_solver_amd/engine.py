@@ -49,7 +49,7 @@ class McfOptions(ctypes.Structure):
         ("abi_version", ctypes.c_int32), ("device", ctypes.c_int32), ("rule", ctypes.c_int32),
         ("batch_pivots", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("profile", ctypes.c_int32),
         ("block_size", ctypes.c_int64), ("shard_rank", ctypes.c_int64), ("shard_count", ctypes.c_int64),
-        ("price_blocks", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("price_blocks", ctypes.c_int32), ("no_fused", ctypes.c_int32),
     ]
 
 
@@ -139,7 +139,7 @@ class McfEngine:
 
     def __init__(self, n: int, tail, head, cost, cap, supply, rule: int = RULE_DANTZIG, block_size: int = 0,
                  batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
-                 shard: tuple[int, int] | None = None, price_blocks: int = 0):
+                 shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -165,6 +165,7 @@ class McfEngine:
         opt.use_graph = 1 if use_graph else 0
         opt.profile = 1 if profile else 0
         opt.price_blocks = int(price_blocks)
+        opt.no_fused = 0 if fused else 1
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule

@@ -21,6 +21,7 @@ namespace {
 struct Emul {
     McfHostImage im;
     std::vector<int32_t> order1, path1, path2;
+    std::vector<McfNode> rec1, rec2;
     std::vector<McfSeg> seg;
     McfCtx ctx;
     McfView view;
@@ -32,6 +33,8 @@ void bind(Emul& e) {
     e.order1 = im.order;
     e.path1.assign(im.n_nodes, 0);
     e.path2.assign(im.n_nodes, 0);
+    e.rec1.assign(im.n_nodes, McfNode{0, 0, 0, 0});
+    e.rec2.assign(im.n_nodes, McfNode{0, 0, 0, 0});
     e.seg.assign(2 * (size_t)im.n_nodes + 2, McfSeg{0, 0, 0});
     std::memset(&e.ctx, 0, sizeof e.ctx);
     e.ctx.unbounded_arc = -1;
@@ -52,6 +55,8 @@ void bind(Emul& e) {
     v.order[1] = e.order1.data();
     v.path1 = e.path1.data();
     v.path2 = e.path2.data();
+    v.rec1 = e.rec1.data();
+    v.rec2 = e.rec2.data();
     v.seg = e.seg.data();
     v.ctx = &e.ctx;
 }

@@ -50,6 +50,24 @@ def test_synthetic_goldens_exact(gpu_engine_module, entry, inst, rule):
     assert np.array_equal(tree["order"], em["order"]) and np.array_equal(tree["parent"], em["parent"])
 
 
+@pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
+def test_fused_lds_path_equals_three_kernel_path(gpu_engine_module, rule):
+    """Small instances run as ONE persistent LDS-resident workgroup; the same instance forced
+    through the three-kernel path (graph and eager) must give the identical pivot sequence."""
+    for idx in (0, 3, 6):
+        _, inst = load_synthetic()[idx]
+        runs = [_solve(gpu_engine_module, inst, rule, fused=True),
+                _solve(gpu_engine_module, inst, rule, fused=False, use_graph=True),
+                _solve(gpu_engine_module, inst, rule, fused=False, use_graph=False, batch_pivots=7)]
+        (r0, t0) = runs[0]
+        assert r0.stats["batches"] <= 2                      # one launch for the whole solve (+ re-arm)
+        for r, t in runs[1:]:
+            assert r.stats["pivots"] == r0.stats["pivots"] and r.objective == r0.objective
+            assert np.array_equal(r.flow, r0.flow) and np.array_equal(r.potential, r0.potential)
+            assert np.array_equal(t["order"], t0["order"]) and np.array_equal(t["parent"], t0["parent"])
+            assert r.stats["arcs_priced"] == r0.stats["arcs_priced"] and r.stats["degenerate"] == r0.stats["degenerate"]
+
+
 # ------------------------------------------------------------------ golden fixtures, through the reference-shaped API
 @pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
 @pytest.mark.parametrize("strategy", ["dantzig", "devex", "adaptive"])
