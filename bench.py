@@ -111,11 +111,17 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         sweep_ms = eng.time_pricing(reps=50)            # back-to-back launches, no events in between
         achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9
         out["kernel_ms"] = {"price": price_ms, "pivot": pivot_ms, "apply": apply_ms, "price_back_to_back": sweep_ms}
+        mode = p1.get("pricing_mode", 0)
+        kname = ("k_price_rc" if mode == 1 else "k_price") + ("<dantzig>" if rule == 0 else "<devex_block>")
+        out["pricing_mode"] = {0: "gather sweep", 1: "resident reduced costs", 2: "fused LDS loop"}.get(mode, str(mode))
         out["roofline"] = {
-            "kernel": "k_price<dantzig>" if rule == 0 else "k_price<devex_block>", "bound": "hbm",
+            "kernel": kname, "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None, "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": sweep_ms,
             "ms_per_launch_in_pivot_loop": price_ms,
+            "note": "achieved = SURVEY section 8d algorithmic bytes (13 B/arc + 8 B/node) / launch time; the resident-rc "
+                    "sweep really moves 9 B/arc, so achieved can exceed the physical peak" if mode == 1 else
+                    "profiled pass runs the three-kernel path (the timed pass of small instances uses the fused LDS loop)",
         }
     eng.close()
     return out

@@ -78,6 +78,8 @@ typedef struct mcf_options {
     int64_t shard_count;     /*   (0 or 1 = all arcs); a shard is 1/shard_count of every XCD head bucket */
     int32_t price_blocks;    /* pricing grid size; 0 = auto */
     int32_t no_fused;        /* 1 = never use the fused LDS-resident kernel for small instances */
+    int32_t no_rcache;       /* 1 = never keep reduced costs resident: always price by gathering potentials */
+    int32_t reserved;
 } mcf_options;
 
 typedef struct mcf_stats {
@@ -101,6 +103,8 @@ typedef struct mcf_stats {
     int64_t price_bytes;      /* algorithmic bytes of one pricing launch: 13 B/arc + 8 B/node (17 for Devex) */
     int64_t artificial_flow;  /* flow still on artificial arcs (> 0 at optimality = infeasible, simplex.py:1573-1624);
                                  -1 when mcf_get_result was asked for neither status, objective nor flow */
+    int64_t pricing_mode;     /* 0 = gather sweep (k_price), 1 = resident reduced costs (k_price_rc + k_rcupd),
+                                 2 = fused LDS-resident pivot loop (k_solve_small) */
 } mcf_stats;
 
 /* Called from mcf_solve every cb_interval pivots (simplex.py:1143-1154).
@@ -160,6 +164,11 @@ int mcf_time_copy(int32_t device, int64_t bytes, int32_t reps, double* ms_per_co
  * parent[n+1], pred_arc[n+1] (-1 for the root), size[n+1], pos[n+1], order[n+1], state[m]. */
 int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
                  int32_t* order, int8_t* state, int64_t* potential_with_root);
+
+/* Reduced cost of every arc (caller's order) as the pricing kernel sees it: the resident copy
+ * when the handle keeps one (*resident = 1), else cost + pi[tail] - pi[head] computed on the host.
+ * Tests use it to check the invariant resident rc == cost + pi[tail] - pi[head]. */
+int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident);
 
 const char* mcf_last_error(mcf_handle* h); /* NULL handle: last create-time error of this thread */
 void mcf_destroy(mcf_handle* h);

@@ -138,6 +138,10 @@ struct McfView {
     McfNode* rec2;          // [n_nodes]
     McfSeg* seg;            // [2*n_nodes + 2] scratch
     McfCtx* ctx;
+    // ---- resident reduced costs (large instances; nullptr = price by gathering potentials)
+    int64_t* rcache;        // [m_pad] rc of every arc under the current potentials, engine order
+    const int64_t* adj_off; // [n_nodes] CSR over real nodes: entries of node u are adj[adj_off[u] .. adj_off[u+1])
+    const int64_t* adj;     // [2m] (other end point << 32) | (engine arc << 1) | (1 when u is the arc's tail)
 };
 
 MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc) {

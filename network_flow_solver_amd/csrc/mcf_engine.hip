@@ -184,6 +184,109 @@ __global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shar
     if (threadIdx.x == 0) cand[blockIdx.x] = McfCand{key, arc};
 }
 
+// ------------------------------------------------------------------ k_price_rc: sweep over RESIDENT reduced costs
+// Large instances keep rc[e] = cost + pi[tail] - pi[head] resident (8 B/arc, exact at all
+// times, see k_rcupd).  The sweep is then a pure coalesced stream -- 8 B rc + 1 B state per arc
+// (+4 B Devex weight), no gathers, no dependence on the potentials -- instead of 13 B/arc plus
+// two random 8-byte gathers that each cost a 128-B L2->L1 line.  Same arc sets (bucket slices),
+// same keys, same tie rule as k_price, so it selects the identical entering arc.
+template <int RULE, bool FILTER>
+__global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t shard, int64_t shards, int use_block,
+                                                             int64_t f_lo, int64_t f_hi, McfCand* __restrict__ cand) {
+    int64_t key = 0, arc = -1;
+    const McfCtx* c = v.ctx;
+    if (c->status == MCF_RUNNING) {
+        const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
+        const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+        int64_t lo, hi;
+        mcf_bucket_slice(v.bucket_off, x, shard, shards, use_block ? c->block_index : 0, use_block ? c->num_blocks : 1,
+                         &lo, &hi);
+        const int64_t g_lo = lo >> 2, g_hi = (hi + 3) >> 2;  // groups of 4 arcs
+        using rc2_t = long2;                                  // two int64 reduced costs per 16-byte load
+        const rc2_t* __restrict__ rc2 = reinterpret_cast<const rc2_t*>(v.rcache);
+        const int32_t* __restrict__ state4 = reinterpret_cast<const int32_t*>(v.state);
+        const float4* __restrict__ w4 = reinterpret_cast<const float4*>(v.weight);
+        const int32_t* __restrict__ orig = v.orig;
+        const int64_t stride = nlb * kPriceThreads;
+        constexpr int U = 4;
+        for (int64_t g0 = g_lo + lb * kPriceThreads + threadIdx.x; g0 < g_hi; g0 += stride * U) {
+            int32_t st[U];
+            rc2_t ra[U], rb[U];
+            float4 w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t g = g0 + u * stride;
+                const bool in = g < g_hi;
+                const int64_t gs = in ? g : g_lo;
+                st[u] = in ? state4[gs] : 0;
+                ra[u] = rc2[2 * gs];
+                rb[u] = rc2[2 * gs + 1];
+                if (RULE == MCF_RULE_DEVEX_BLOCK) w[u] = w4[gs];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t rcs[4] = {ra[u].x, ra[u].y, rb[u].x, rb[u].y};
+                const float ws[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+                const int64_t g = g0 + u * stride;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t s = (int32_t)(int8_t)(st[u] >> (8 * k));
+                    const int64_t i = (g << 2) + k;
+                    if (s == 0 || i < lo || i >= hi) continue;
+                    const int64_t viol = -(int64_t)s * rcs[k];
+                    if (viol <= 0) continue;
+                    int64_t kk = viol;
+                    if (RULE == MCF_RULE_DEVEX_BLOCK) {
+                        const double merit = ((double)viol * (double)viol) / (double)ws[k];
+                        kk = __double_as_longlong(merit);
+                    }
+                    if (kk < key) continue;              // cannot win: skip the id lookup
+                    const int32_t o = orig[i];
+                    if (FILTER && (o < f_lo || o >= f_hi)) continue;
+                    const int64_t id = mcf_pack_arc(o, i);
+                    if (mcf_cand_better(kk, id, key, arc)) { key = kk; arc = id; }
+                }
+            }
+        }
+    }
+    block_argmax<kPriceThreads>(key, arc);
+    if (threadIdx.x == 0) cand[blockIdx.x] = McfCand{key, arc};
+}
+
+// ------------------------------------------------------------------ k_rcupd: keep the resident reduced costs exact
+// Runs after k_apply.  The swap shifted the potentials of the re-hung subtree T2 -- now the
+// contiguous slice order[b .. b+S) -- by sigma, so an arc changes iff exactly one end point is in
+// T2: +sigma when its tail is inside, -sigma when its head is.  16 lanes per T2 node walk its
+// CSR adjacency; every such arc is visited exactly once (from its inside end), so no atomics.
+constexpr int kRcupdThreads = 256;
+constexpr int kMaxRcupdBlocks = 1024;
+
+__global__ __launch_bounds__(kRcupdThreads) void k_rcupd(McfView v) {
+    const McfCtx* c = v.ctx;
+    if (!c->apply) return;
+    const int32_t b = c->t2_new, S = c->t2_size;
+    const int64_t sigma = c->sigma;
+    const int32_t* __restrict__ ord = c->cur ? v.order[0] : v.order[1];  // the copy k_apply just wrote
+    const int64_t* __restrict__ adj_off = v.adj_off;
+    const int64_t* __restrict__ adj = v.adj;
+    const McfNode* __restrict__ node = v.node;
+    int64_t* __restrict__ rcache = v.rcache;
+    const int32_t sub = threadIdx.x & 15;
+    const int64_t ngroups = (int64_t)gridDim.x * (kRcupdThreads / 16);
+    for (int64_t t = (int64_t)blockIdx.x * (kRcupdThreads / 16) + (threadIdx.x >> 4); t < S; t += ngroups) {
+        const int32_t u = ord[b + t];
+        const int64_t beg = adj_off[u], end = adj_off[u + 1];
+        for (int64_t p = beg + sub; p < end; p += 16) {
+            const int64_t ent = adj[p];
+            const int32_t w = (int32_t)(ent >> 32);
+            const int32_t pw = node[w].pos;
+            if (pw >= b && pw < b + S) continue;  // both ends inside T2: unchanged
+            const int32_t e = (int32_t)((uint32_t)ent >> 1);
+            rcache[e] += (ent & 1) ? sigma : -sigma;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ k_reduce (multi-GPU: local best -> 16 bytes)
 __global__ __launch_bounds__(kPivotThreads) void k_reduce(const McfCand* __restrict__ cand, int ncand,
                                                            McfCand* __restrict__ out) {
@@ -434,6 +537,9 @@ struct mcf_handle {
     McfNode* d_node = nullptr;
     int32_t *d_order0 = nullptr, *d_order1 = nullptr, *d_path1 = nullptr, *d_path2 = nullptr;
     McfNode *d_rec1 = nullptr, *d_rec2 = nullptr;
+    int64_t *d_rcache = nullptr, *d_adj_off = nullptr, *d_adj = nullptr;
+    bool rcached = false;     // large instance: resident reduced costs + k_rcupd
+    int rcupd_blocks = 1;
     McfSeg* d_seg = nullptr;
     McfCtx* d_ctx = nullptr;
     McfCand* d_cand = nullptr;
@@ -494,6 +600,8 @@ int upload_image(mcf_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->d_node, im.node.data(), im.node.size() * sizeof(McfNode), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_order0, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_order1, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->rcached)
+        HIP_TRY(h, hipMemcpyAsync(h->d_rcache, im.rcache.data(), im.m_pad * 8, hipMemcpyHostToDevice, h->stream));
     McfCtx c;
     std::memset(&c, 0, sizeof c);
     c.unbounded_arc = -1;
@@ -524,19 +632,31 @@ int upload_image(mcf_handle* h) {
 }
 
 void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, int use_block) {
-    if (rule == MCF_RULE_DEVEX_BLOCK)
-        hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, false>), dim3(h->price_blocks), dim3(kPriceThreads), 0, s, v, h->shard,
-                           h->shards, use_block, (int64_t)0, (int64_t)0, h->d_cand);
-    else
-        hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, false>), dim3(h->price_blocks), dim3(kPriceThreads), 0, s, v, h->shard,
-                           h->shards, 0, (int64_t)0, (int64_t)0, h->d_cand);
+    const dim3 grid(h->price_blocks), block(kPriceThreads);
+    const int64_t z = 0;
+    if (h->rcached) {
+        if (rule == MCF_RULE_DEVEX_BLOCK)
+            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, h->d_cand);
+        else
+            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false>), grid, block, 0, s, v, h->shard, h->shards, 0, z, z, h->d_cand);
+    } else {
+        if (rule == MCF_RULE_DEVEX_BLOCK)
+            hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, h->d_cand);
+        else
+            hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, false>), grid, block, 0, s, v, h->shard, h->shards, 0, z, z, h->d_cand);
+    }
+}
+
+void launch_apply(mcf_handle* h, hipStream_t s) {
+    hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
+    if (h->rcached) hipLaunchKernelGGL(k_rcupd, dim3(h->rcupd_blocks), dim3(kRcupdThreads), 0, s, h->view);
 }
 
 void launch_pivot_triplet(mcf_handle* h, hipStream_t s) {
     const int32_t rule = h->opt.rule;
     launch_price(h, s, h->view, rule, rule == MCF_RULE_DEVEX_BLOCK);
     hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, h->d_cand, h->price_blocks, rule);
-    hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
+    launch_apply(h, s);
 }
 
 int build_graph(mcf_handle* h, int batch) {
@@ -567,7 +687,7 @@ int run_batch_profiled(mcf_handle* h, int batch) {
         HIP_TRY(h, hipEventRecord(ev[1], h->stream));
         hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, h->stream, h->view, h->d_cand, h->price_blocks, rule);
         HIP_TRY(h, hipEventRecord(ev[2], h->stream));
-        hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, h->stream, h->view);
+        launch_apply(h, h->stream);
         HIP_TRY(h, hipEventRecord(ev[3], h->stream));
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -727,6 +847,22 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
             if (fe != hipSuccess) h->small = false;  // fall back to the three-kernel GPU path
         }
     }
+    // resident reduced costs for everything that does not take the fused LDS path
+    h->rcached = !h->small && !opt.no_rcache && im.m > 0;
+    if (h->rcached) {
+        mcf_build_rcache(h->im);
+        if ((e = dalloc(&h->d_rcache, im.m_pad)) != hipSuccess) return fail("hipMalloc rcache", e);
+        if ((e = dalloc(&h->d_adj_off, im.adj_off.size())) != hipSuccess) return fail("hipMalloc adj_off", e);
+        if ((e = dalloc(&h->d_adj, im.adj.size())) != hipSuccess) return fail("hipMalloc adj", e);
+        if ((e = hipMemcpy(h->d_adj_off, im.adj_off.data(), im.adj_off.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("copy adj_off", e);
+        if ((e = hipMemcpy(h->d_adj, im.adj.data(), im.adj.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("copy adj", e);
+        h->im.adj.clear(); h->im.adj.shrink_to_fit();  // the device copy is the only one needed from here on
+        v.rcache = h->d_rcache; v.adj_off = h->d_adj_off; v.adj = h->d_adj;
+        const int64_t rb = ((int64_t)im.n_nodes + 15) / 16;  // one 16-lane group per node of the largest possible T2
+        h->rcupd_blocks = (int)(rb < kMaxRcupdBlocks ? (rb > 0 ? rb : 1) : kMaxRcupdBlocks);
+    } else {
+        v.rcache = nullptr; v.adj_off = nullptr; v.adj = nullptr;
+    }
     const int rc = upload_image(h);
     if (rc != MCF_OK) { g_create_error = h->err; free_all(h); delete h; return rc; }
     *out = h;
@@ -855,6 +991,7 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
         h->stats.subtree_nodes = c.subtree_nodes; h->stats.cycle_arcs = c.cycle_arcs;
         h->stats.unbounded_arc = c.unbounded_arc >= 0 ? im.orig[c.unbounded_arc] : -1;
         h->stats.artificial_flow = r.artificial_flow;
+        h->stats.pricing_mode = h->small ? 2 : (h->rcached ? 1 : 0);
         h->stats.unbounded_rc = 0;
         if (c.status == MCF_UNBOUNDED && c.unbounded_arc >= 0) {
             std::vector<int64_t> pi(im.n_nodes);
@@ -882,12 +1019,21 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
     int32_t running = MCF_RUNNING;
     HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &running, 4, hipMemcpyHostToDevice, h->stream));
     // whole arc list (shard 0 of 1), restricted to ORIGINAL indices [start, end)
-    if (rule == MCF_RULE_DEVEX_BLOCK)
-        hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, true>), dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v,
-                           (int64_t)0, (int64_t)1, 0, start, end, h->d_cand);
-    else
-        hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, true>), dim3(h->price_blocks), dim3(kPriceThreads), 0, h->stream, v,
-                           (int64_t)0, (int64_t)1, 0, start, end, h->d_cand);
+    {
+        const dim3 grid(h->price_blocks), block(kPriceThreads);
+        const int64_t z = 0, one = 1;
+        if (h->rcached) {
+            if (rule == MCF_RULE_DEVEX_BLOCK)
+                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand);
+            else
+                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand);
+        } else {
+            if (rule == MCF_RULE_DEVEX_BLOCK)
+                hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand);
+            else
+                hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand);
+        }
+    }
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, h->stream, h->d_cand, h->price_blocks, h->d_one);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &saved, 4, hipMemcpyHostToDevice, h->stream));
@@ -923,7 +1069,7 @@ int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, reinterpret_cast<const McfCand*>(cands_dev), ncand,
                        h->opt.rule);
-    hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
+    launch_apply(h, s);
     HIP_TRY(h, hipGetLastError());
     return MCF_OK;
 }
@@ -1026,6 +1172,24 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
         for (int64_t i = 0; i < im.m; ++i) state[im.orig[i]] = st[i];
     }
     if (potential_with_root) HIP_TRY(h, hipMemcpy(potential_with_root, h->d_pi, (size_t)im.n_nodes * 8, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
+
+int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident) {
+    if (!h || !rc_out) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const McfHostImage& im = h->im;
+    if (resident) *resident = h->rcached ? 1 : 0;
+    if (h->rcached) {
+        std::vector<int64_t> rc(im.m_pad);
+        HIP_TRY(h, hipMemcpy(rc.data(), h->d_rcache, rc.size() * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < im.m; ++i) rc_out[im.orig[i]] = rc[i];
+    } else {
+        std::vector<int64_t> pi(im.n_nodes);
+        HIP_TRY(h, hipMemcpy(pi.data(), h->d_pi, pi.size() * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < im.m; ++i) rc_out[im.orig[i]] = im.cost64[i] + pi[im.tail[i]] - pi[im.head[i]];
+    }
     return MCF_OK;
 }
 

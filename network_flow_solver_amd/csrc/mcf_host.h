@@ -32,6 +32,10 @@ struct McfHostImage {
     std::vector<McfNode> node;              // [n_nodes]
     std::vector<int32_t> order;             // [n_nodes]
     std::vector<int64_t> supply;            // [n]
+    // resident reduced costs + node->arc adjacency (mcf_build_rcache)
+    std::vector<int64_t> rcache;            // [m_pad]
+    std::vector<int64_t> adj_off;           // [n + 1]
+    std::vector<int64_t> adj;               // [2m]
 };
 
 // Validate the caller's arrays and build the start basis.  Returns "" or an error text.
@@ -138,6 +142,27 @@ inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, co
     }
     *err_code = 0;
     return "";
+}
+
+// Resident reduced costs for the start basis and the CSR adjacency the update kernel walks.
+// rc[e] = cost + pi[tail] - pi[head] (simplex.py:508-512), kept exact for every arc from here on:
+// a basis swap shifts the potentials of the re-hung subtree T2 by sigma, so exactly the arcs
+// with one end point in T2 change, by +sigma (tail inside) or -sigma (head inside).
+inline void mcf_build_rcache(McfHostImage& im) {
+    const int64_t m = im.m;
+    const int32_t n = im.n;
+    im.rcache.assign(im.m_pad, 0);
+    for (int64_t e = 0; e < m; ++e) im.rcache[e] = (int64_t)im.cost[e] + im.pi[im.tail[e]] - im.pi[im.head[e]];
+    im.adj_off.assign((size_t)n + 1, 0);
+    for (int64_t e = 0; e < m; ++e) { im.adj_off[im.tail[e] + 1]++; im.adj_off[im.head[e] + 1]++; }
+    for (int32_t v = 0; v < n; ++v) im.adj_off[v + 1] += im.adj_off[v];
+    im.adj.assign((size_t)(2 * m), 0);
+    std::vector<int64_t> fill(im.adj_off.begin(), im.adj_off.end() - 1);
+    for (int64_t e = 0; e < m; ++e) {
+        const int64_t t = im.tail[e], h = im.head[e];
+        im.adj[fill[t]++] = (h << 32) | (e << 1) | 1;
+        im.adj[fill[h]++] = (t << 32) | (e << 1);
+    }
 }
 
 struct McfHostResult {

@@ -28,7 +28,7 @@ CAP_INF = -1
 ABI_SYMBOLS = (
     "mcf_default_options", "mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset",
     "mcf_enqueue_price", "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing",
-    "mcf_time_copy", "mcf_get_tree", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
+    "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
 )
 
 
@@ -49,7 +49,8 @@ class McfOptions(ctypes.Structure):
         ("abi_version", ctypes.c_int32), ("device", ctypes.c_int32), ("rule", ctypes.c_int32),
         ("batch_pivots", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("profile", ctypes.c_int32),
         ("block_size", ctypes.c_int64), ("shard_rank", ctypes.c_int64), ("shard_count", ctypes.c_int64),
-        ("price_blocks", ctypes.c_int32), ("no_fused", ctypes.c_int32),
+        ("price_blocks", ctypes.c_int32), ("no_fused", ctypes.c_int32), ("no_rcache", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -61,7 +62,7 @@ class McfStats(ctypes.Structure):
         ("unbounded_rc", ctypes.c_int64), ("solve_seconds", ctypes.c_double), ("price_ms", ctypes.c_double),
         ("pivot_ms", ctypes.c_double), ("apply_ms", ctypes.c_double), ("price_launches", ctypes.c_int64),
         ("pivot_launches", ctypes.c_int64), ("apply_launches", ctypes.c_int64), ("price_bytes", ctypes.c_int64),
-        ("artificial_flow", ctypes.c_int64),
+        ("artificial_flow", ctypes.c_int64), ("pricing_mode", ctypes.c_int64),
     ]
 
     def as_dict(self) -> dict:
@@ -102,13 +103,14 @@ def load_library():
     lib.mcf_time_pricing.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     lib.mcf_time_copy.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     lib.mcf_get_tree.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i8p, i64p]
+    lib.mcf_get_reduced_costs.argtypes = [vp, i64p, i32p]
     lib.mcf_last_error.argtypes = [vp]
     lib.mcf_last_error.restype = ctypes.c_char_p
     lib.mcf_destroy.argtypes = [vp]
     lib.mcf_destroy.restype = None
     for name in ("mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_enqueue_price",
                  "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing", "mcf_time_copy",
-                 "mcf_get_tree"):
+                 "mcf_get_tree", "mcf_get_reduced_costs"):
         getattr(lib, name).restype = ctypes.c_int
     if lib.mcf_abi_version() != 1:
         raise EngineUnavailableError("libmcf_hip.so ABI version mismatch")
@@ -139,7 +141,8 @@ class McfEngine:
 
     def __init__(self, n: int, tail, head, cost, cap, supply, rule: int = RULE_DANTZIG, block_size: int = 0,
                  batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
-                 shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True):
+                 shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
+                 resident_rc: bool = True):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -166,6 +169,7 @@ class McfEngine:
         opt.profile = 1 if profile else 0
         opt.price_blocks = int(price_blocks)
         opt.no_fused = 0 if fused else 1
+        opt.no_rcache = 0 if resident_rc else 1
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule
@@ -262,6 +266,13 @@ class McfEngine:
                                            _p(order, i32), _p(state, ctypes.c_int8), _p(pi, ctypes.c_int64)))
         return {"parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order,
                 "state": state[: self.m], "pi": pi}
+
+    def reduced_costs(self):
+        """(rc[m] in caller order, resident?) -- what the pricing kernel reads."""
+        rc = np.zeros(max(self.m, 1), dtype=np.int64)
+        res = ctypes.c_int32(0)
+        self._check(self._lib.mcf_get_reduced_costs(self._h, _p(rc, ctypes.c_int64), ctypes.byref(res)))
+        return rc[: self.m], bool(res.value)
 
     # -- measurement
     def time_pricing(self, reps: int = 20, rule: int | None = None) -> float:

@@ -59,6 +59,9 @@ void bind(Emul& e) {
     v.rec2 = e.rec2.data();
     v.seg = e.seg.data();
     v.ctx = &e.ctx;
+    v.rcache = nullptr;  // the emulation always prices by gathering potentials: an independent
+    v.adj_off = nullptr; // check of the engine's resident reduced costs
+    v.adj = nullptr;
 }
 
 // scalar stand-in for the pricing kernel: shard r of G, Devex block = ctx.block_index of

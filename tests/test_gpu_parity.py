@@ -68,6 +68,32 @@ def test_fused_lds_path_equals_three_kernel_path(gpu_engine_module, rule):
             assert r.stats["arcs_priced"] == r0.stats["arcs_priced"] and r.stats["degenerate"] == r0.stats["degenerate"]
 
 
+@pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
+def test_resident_reduced_costs_stay_exact(gpu_engine_module, rule):
+    """Large instances price from RESIDENT reduced costs that k_rcupd patches after every basis
+    swap.  Invariant: the resident copy equals cost + pi[tail] - pi[head] for every arc, at every
+    stage of the solve; and the pivot sequence equals the gather-priced one."""
+    _, inst = load_synthetic()[7]                                  # 1 024 nodes / 8 192 arcs: past the LDS path
+    e = gpu_engine_module
+    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule) as eng:
+        for budget in (0, 1, 5, 40, 300, 10 ** 9):
+            if budget:
+                eng.solve(max_pivots=budget)
+            rc, resident = eng.reduced_costs()
+            assert resident
+            pi = eng.tree()["pi"]
+            assert np.array_equal(rc, inst.cost + pi[inst.tail] - pi[inst.head])
+        res, tree = eng.result(), eng.tree()
+    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule,
+                     resident_rc=False) as eng:
+        eng.solve()
+        assert not eng.reduced_costs()[1]
+        ref, rtree = eng.result(), eng.tree()
+    assert res.status == ref.status == "optimal" and res.stats["pivots"] == ref.stats["pivots"]
+    assert np.array_equal(res.flow, ref.flow) and np.array_equal(res.potential, ref.potential)
+    assert np.array_equal(tree["order"], rtree["order"]) and res.stats["arcs_priced"] == ref.stats["arcs_priced"]
+
+
 # ------------------------------------------------------------------ golden fixtures, through the reference-shaped API
 @pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
 @pytest.mark.parametrize("strategy", ["dantzig", "devex", "adaptive"])
@@ -252,6 +278,8 @@ def test_baseline_sizes_certified_optimal(gpu_engine_module, name, rule):
     assert (pos[parent[v]] < pos[v]).all() and (pos[v] + size[v] <= pos[parent[v]] + size[parent[v]]).all()
     assert np.array_equal(np.bincount(parent[v], weights=size[v], minlength=n + 1).astype(np.int64) + 1, size)
     if name == "netgen_8_14a":                                    # the other rule must land on the same optimum
+        pass
+    if name == "netgen_8_14a":
         other, _ = _solve(gpu_engine_module, inst, 1)
         assert other.objective == res.objective
 
