@@ -114,11 +114,19 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         mode = p1.get("pricing_mode", 0)
         kname = ("k_price_rc" if mode == 1 else "k_price") + ("<dantzig>" if rule == 0 else "<devex_block>")
         out["pricing_mode"] = {0: "gather sweep", 1: "resident reduced costs", 2: "fused LDS loop"}.get(mode, str(mode))
+        traffic, traffic_src = None, None
+        try:  # PMC traffic is collected offline (rocprofv3 --pmc passes) and committed under profiles/
+            table = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+            hit = table.get(f"{workload}|{out['pricing_mode']}")
+            if hit:
+                traffic, traffic_src = hit["bytes_per_launch"], hit["source"]
+        except Exception:
+            pass
         out["roofline"] = {
             "kernel": kname, "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None, "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": sweep_ms,
-            "ms_per_launch_in_pivot_loop": price_ms,
+            "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": int(bytes_per_launch),
+            "ms_per_launch": sweep_ms, "ms_per_launch_in_pivot_loop": price_ms,
             "note": "achieved = SURVEY section 8d algorithmic bytes (13 B/arc + 8 B/node) / launch time; the resident-rc "
                     "sweep really moves 9 B/arc, so achieved can exceed the physical peak" if mode == 1 else
                     "profiled pass runs the three-kernel path (the timed pass of small instances uses the fused LDS loop)",
@@ -171,7 +179,7 @@ def main():
     rule = 0 if args.rule == "dantzig" else 1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("MCF_BENCH_FORCE_DIST") == "1":  # env: rehearse the sharded path on 1 GPU
         from network_flow_solver_amd import distributed
 
         distributed.bench_main(args, WORKLOADS, HBM_PEAK_GBPS)

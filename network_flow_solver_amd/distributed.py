@@ -78,7 +78,7 @@ class HipShardEngine:
         self.eng.close()
 
 
-def run_pivots(eng, dist, world: int, max_total_pivots: int, batch: int = 32, group=None):
+def run_pivots(eng, dist, world: int, max_total_pivots: int, batch: int = 32, group=None, always_gather: bool = False):
     """Pivot until the replicas report a final status or `max_total_pivots` pivots were made.
 
     Returns (status, pivots): status in the MCF_ST_* numbering (0 optimal-or-infeasible,
@@ -88,7 +88,7 @@ def run_pivots(eng, dist, world: int, max_total_pivots: int, batch: int = 32, gr
     while True:
         for _ in range(batch):
             eng.price_local(local)
-            if world > 1:
+            if world > 1 or always_gather:
                 dist.all_gather_into_tensor(gathered, local, group=group)
                 eng.pivot(gathered, world)
             else:
@@ -124,12 +124,13 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         # weak scaling: per-GPU arcs fixed, the instance grows with the number of GPUs
         inst = generators.netgen_style(n1 * world, m1 * world, seed=1, name=f"{wl}(synthetic,x{world})")
         eng = HipShardEngine(inst, rule, rank, world, local_rank)
-        run_pivots(eng, dist, world, warmup)
+        force = os.environ.get("MCF_BENCH_FORCE_DIST") == "1"  # 1-GPU rehearsal: still issue the collective
+        run_pivots(eng, dist, world, warmup, always_gather=force)
         _, p0 = eng.poll()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        status, p1 = run_pivots(eng, dist, world, p0 + steps)
+        status, p1 = run_pivots(eng, dist, world, p0 + steps, always_gather=force)
         torch.cuda.synchronize()
         dist.barrier()
         dt = time.perf_counter() - t0
