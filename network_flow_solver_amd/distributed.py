@@ -78,24 +78,71 @@ class HipShardEngine:
         self.eng.close()
 
 
-def run_pivots(eng, dist, world: int, max_total_pivots: int, batch: int = 32, group=None, always_gather: bool = False):
-    """Pivot until the replicas report a final status or `max_total_pivots` pivots were made.
+def _enqueue_batch(eng, dist, world, local, gathered, batch, group, gather):
+    for _ in range(batch):
+        eng.price_local(local)
+        if gather:
+            dist.all_gather_into_tensor(gathered, local, group=group)
+            eng.pivot(gathered, world)
+        else:
+            eng.pivot(local, 1)
 
-    Returns (status, pivots): status in the MCF_ST_* numbering (0 optimal-or-infeasible,
-    2 iteration limit, 3 unbounded)."""
-    local, gathered = eng.new_candidate_buffers(world)
-    eng.set_max_pivots(max_total_pivots)
-    while True:
-        for _ in range(batch):
-            eng.price_local(local)
-            if world > 1 or always_gather:
-                dist.all_gather_into_tensor(gathered, local, group=group)
-                eng.pivot(gathered, world)
+
+class PivotLoop:
+    """`batch` pivots per host round trip; optionally replayed from a captured graph.
+
+    Graph mode (GPU engines only) captures price -> all-gather -> pivot x batch once on a side
+    stream (RCCL collectives are capturable) and replays it, which removes the per-pivot host
+    cost of the eager loop (two kernel enqueues + one torch.distributed call, ~40 us).  Any
+    failure while capturing falls back to the eager loop."""
+
+    def __init__(self, eng, dist, world: int, batch: int = 32, group=None, always_gather: bool = False,
+                 use_graph: bool = False):
+        self.eng, self.dist, self.world, self.batch, self.group = eng, dist, world, batch, group
+        self.gather = world > 1 or always_gather
+        self.local, self.gathered = eng.new_candidate_buffers(world)
+        self.graph = None
+        self.graph_error = None
+        if use_graph and hasattr(eng, "torch"):
+            self._try_capture()
+
+    def _try_capture(self):
+        torch = self.eng.torch
+        try:
+            # one eager batch first: communicator set-up and lazy allocations must not be captured
+            _enqueue_batch(self.eng, self.dist, self.world, self.local, self.gathered, 1, self.group, self.gather)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                _enqueue_batch(self.eng, self.dist, self.world, self.local, self.gathered, self.batch, self.group,
+                               self.gather)
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = g
+        except Exception as exc:  # capture unsupported here: stay eager
+            self.graph = None
+            self.graph_error = f"{type(exc).__name__}: {exc}"
+            torch.cuda.synchronize()
+
+    def run(self, max_total_pivots: int):
+        """Pivot until a final status or `max_total_pivots`; returns (status, pivots) with status in
+        the MCF_ST_* numbering (0 optimal-or-infeasible, 2 iteration limit, 3 unbounded)."""
+        self.eng.set_max_pivots(max_total_pivots)
+        while True:
+            if self.graph is not None:
+                self.graph.replay()
             else:
-                eng.pivot(local, 1)
-        status, pivots = eng.poll()
-        if status is not None:
-            return status, pivots
+                _enqueue_batch(self.eng, self.dist, self.world, self.local, self.gathered, self.batch, self.group,
+                               self.gather)
+            status, pivots = self.eng.poll()
+            if status is not None:
+                return status, pivots
+
+
+def run_pivots(eng, dist, world: int, max_total_pivots: int, batch: int = 32, group=None, always_gather: bool = False):
+    """Eager convenience wrapper (used by the gloo tests)."""
+    return PivotLoop(eng, dist, world, batch, group, always_gather).run(max_total_pivots)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -107,6 +154,10 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
 
     from . import generators
 
+    # RCCL prints a version banner on stdout when the communicator comes up; the contract is ONE
+    # JSON line on stdout, so everything else that lands on fd 1 is sent to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -125,12 +176,14 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         inst = generators.netgen_style(n1 * world, m1 * world, seed=1, name=f"{wl}(synthetic,x{world})")
         eng = HipShardEngine(inst, rule, rank, world, local_rank)
         force = os.environ.get("MCF_BENCH_FORCE_DIST") == "1"  # 1-GPU rehearsal: still issue the collective
-        run_pivots(eng, dist, world, warmup, always_gather=force)
+        loop = PivotLoop(eng, dist, world, batch=32, always_gather=force,
+                         use_graph=os.environ.get("MCF_DIST_GRAPH", "1") == "1")  # MCF_DIST_GRAPH=0: eager loop
+        loop.run(warmup)
         _, p0 = eng.poll()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        status, p1 = run_pivots(eng, dist, world, p0 + steps, always_gather=force)
+        status, p1 = loop.run(p0 + steps)
         torch.cuda.synchronize()
         dist.barrier()
         dt = time.perf_counter() - t0
@@ -146,6 +199,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         return {"workload": f"{inst.name}: {inst.n} nodes / {inst.m} arcs, {shard_arcs} arcs per GPU", "pivots": pivots,
                 "seconds": dt, "pivots_per_sec": pivots / dt, "arcs_priced_per_sec": pivots * inst.m / dt,
                 "ms_per_step": 1e3 * dt / max(pivots, 1), "completed": status == 2,
+                "pivot_loop": "captured graph" if loop.graph is not None else "eager", "graph_error": loop.graph_error,
                 "roofline": {"kernel": "k_price (per-rank shard)", "bound": "hbm", "achieved": achieved,
                              "peak": hbm_peak_gbps, "unit": "GB/s", "frac": achieved / hbm_peak_gbps, "traffic": None,
                              "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": sweep_ms}}
@@ -158,15 +212,16 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": head["workload"], "pricing": "full-scan Dantzig" if rule == 0 else "block-search Devex",
                    "step": "one pivot (sharded price + 16 B all-gather + replicated tree/potential update)",
-                   "parallelism": f"arc-sharded x{world}, replicated tree, 1 RCCL all-gather per pivot"},
+                   "parallelism": f"arc-sharded x{world}, replicated tree, 1 RCCL all-gather per pivot",
+                   "pivot_loop": head["pivot_loop"], "graph_error": head["graph_error"]},
         "roofline": head["roofline"],
     }
     if not args.no_hbm_point and workload == "netgen_8_08a":
         big = measure("netgen_8_18a" if "netgen_8_18a" in workloads else "netgen_8_16a", min(args.steps, 200), min(args.warmup, 20))
-        line["hbm_point"] = {k: big[k] for k in ("workload", "pivots_per_sec", "ms_per_step", "roofline")}
+        line["hbm_point"] = {k: big[k] for k in ("workload", "pivots_per_sec", "ms_per_step", "roofline", "pivot_loop")}
         line["hbm_point"]["value"] = big["arcs_priced_per_sec"]
         line["hbm_point"]["unit"] = "arcs/s"
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()
