@@ -125,6 +125,49 @@ def test_small_cases_through_the_shim(gpu_engine_module, case, strategy):
     assert res.basis is not None and all(k in {(a["tail"], a["head"]) for a in case["arcs"]} for k in res.basis.tree_arcs)
 
 
+# ------------------------------------------------------------------ randomised API-level parity
+@pytest.mark.parametrize("seed", list(range(0, 160, 2)))
+def test_random_problems_through_the_shim(gpu_engine_module, seed):
+    """Negative costs, zero / unlimited capacities, lower bounds, parallel arcs, undirected edges,
+    fractional data, infeasible demands -- through solve_min_cost_flow on the GPU, against an
+    independent exact solve (networkx) and the oracle wherever the reference is self-consistent
+    (see tests/test_random_cpu.py for the two reference defects this input family exposes)."""
+    from random_instances import make
+    from test_random_cpu import networkx_truth
+
+    nodes, arcs, directed = make(seed)
+    problem = nfs.build_problem(nodes, arcs, directed, 1e-6)
+    truth_status, truth_obj = networkx_truth(problem)
+    for strategy in ("dantzig", "devex"):
+        opts = nfs.SolverOptions(pricing_strategy=strategy, explicit_pricing_strategy=True)
+        if truth_status == "unbounded":
+            with pytest.raises(nfs.UnboundedProblemError):
+                nfs.solve_min_cost_flow(problem, opts)
+            continue
+        res = nfs.solve_min_cost_flow(problem, opts)
+        assert res.status == truth_status
+        if truth_status == "infeasible":
+            assert res.flows == {} and res.objective == 0.0
+            continue
+        assert res.objective == pytest.approx(truth_obj, abs=1e-7)
+        # feasibility of the reported flows in the caller's terms (bounds + conservation)
+        bal = {nd["id"]: nd["supply"] for nd in nodes}
+        by_key = {}
+        for a in arcs:
+            by_key.setdefault((a["tail"], a["head"]), []).append(a)
+        for (t, h), f in res.flows.items():
+            lo = sum((-x["capacity"] if not directed else x["lower"]) for x in by_key[(t, h)])
+            hi = sum((float("inf") if x["capacity"] is None else x["capacity"]) for x in by_key[(t, h)])
+            assert lo - 1e-9 <= f <= hi + 1e-9
+            bal[t] -= f
+            bal[h] += f
+        assert all(abs(v) <= 1e-9 for v in bal.values())
+    ref = oracle.solve_dicts(nodes, arcs, directed, 1e-6, "dantzig")
+    refx = oracle.solve_dicts(nodes, arcs, directed, 1e-6, "devex")
+    if ref.status == refx.status == "optimal":
+        assert ref.objective == pytest.approx(truth_obj, abs=1e-7)
+
+
 # ------------------------------------------------------------------ fresh seeds vs the oracle
 @pytest.mark.parametrize("seed", [11, 12, 13])
 @pytest.mark.parametrize("family", ["netgen", "gridgen", "goto"])
