@@ -179,17 +179,24 @@ class NetworkSimplex:
         start = time.time()
 
         progress = None
+        raised: list[BaseException] = []
         if progress_callback is not None:
             def progress(pivots: int, cap: int, elapsed: float):
                 res = self.engine.result()
                 phase = 1 if res.stats["artificial_flow"] > 0 else 2
-                progress_callback(ProgressInfo(iteration=pivots, max_iterations=max_iterations, phase=phase,
-                                               phase_iterations=pivots,
-                                               objective_estimate=self._objective_estimate(res.flow),
-                                               elapsed_time=time.time() - start))
+                try:
+                    progress_callback(ProgressInfo(iteration=pivots, max_iterations=max_iterations, phase=phase,
+                                                   phase_iterations=pivots,
+                                                   objective_estimate=self._objective_estimate(res.flow),
+                                                   elapsed_time=time.time() - start))
+                except BaseException as exc:  # an exception cannot cross the C boundary: stop the solve, re-raise after
+                    raised.append(exc)
+                    return True
                 return False
 
         self.engine.solve(max_iterations, progress, progress_interval)
+        if raised:
+            raise raised[0]
         res = self.engine.result()
         self.stats = res.stats
         iterations = int(res.stats["pivots"])

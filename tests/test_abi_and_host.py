@@ -171,3 +171,15 @@ def test_generators_are_deterministic_and_balanced():
     assert np.all(np.diff(a.tail.astype(np.int64) * a.n + a.head) > 0)        # tail-major, no duplicates
     for inst in (g.gridgen_style(8, 8, 1), g.goto_style(8, 8, 1)):
         assert inst.m == 8 * inst.n and int(inst.supply.sum()) == 0 and (inst.tail != inst.head).all()
+
+
+def test_solver_adapter_never_raises_and_reports_availability():
+    from network_flow_solver_amd.adapter import Mi355xAdapter, SolverResult
+
+    assert Mi355xAdapter.name == "network_solver_mi355x" and isinstance(Mi355xAdapter.get_version(), str)
+    assert Mi355xAdapter.is_available() == (engine.load_library().mcf_device_count() > 0)
+    c = CASES[0]
+    res = Mi355xAdapter.solve(nfs.build_problem(c["nodes"], c["arcs"], c["directed"], c["tolerance"]))
+    assert isinstance(res, SolverResult)
+    if not Mi355xAdapter.is_available():
+        assert res.status == "error" and "EngineUnavailableError" in res.error_message   # loud, but not an exception

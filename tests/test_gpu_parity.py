@@ -168,6 +168,22 @@ def test_random_problems_through_the_shim(gpu_engine_module, seed):
         assert ref.objective == pytest.approx(truth_obj, abs=1e-7)
 
 
+def test_solver_adapter_on_gpu(gpu_engine_module):
+    from network_flow_solver_amd.adapter import Mi355xAdapter
+
+    assert Mi355xAdapter.is_available()
+    for name, want in (("sample_problem", 15.0), ("textbook_transport", 85.0), ("infeasible_capacity_starved", None)):
+        case = next(c for c in CASES if c["name"] == name)
+        res = Mi355xAdapter.solve(nfs.build_problem(case["nodes"], case["arcs"], case["directed"], case["tolerance"]))
+        if want is None:
+            assert res.status == "infeasible" and res.objective is None
+        else:
+            assert res.status == "optimal" and res.objective == pytest.approx(want) and res.iterations > 0
+    case = next(c for c in CASES if c["name"] == "unbounded_cycle")
+    res = Mi355xAdapter.solve(nfs.build_problem(case["nodes"], case["arcs"], True, 1e-9))
+    assert res.status == "unbounded"
+
+
 # ------------------------------------------------------------------ fresh seeds vs the oracle
 @pytest.mark.parametrize("seed", [11, 12, 13])
 @pytest.mark.parametrize("family", ["netgen", "gridgen", "goto"])
