@@ -41,6 +41,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (/opt/skills/guides/MI355X
 WORKLOADS = {
     # name: (family builder args) -- per-GPU shape; at N GPUs the instance has N x the arcs and nodes
     "netgen_8_08a": ("netgen", 256, 2048),
+    "gridgen_8_14a": ("gridgen", 128, 128),      # BASELINE.json configs[2]: 16 385 nodes / 131 080 arcs
+    "goto_8_16a": ("goto", 256, 256),            # BASELINE.json configs[3]: 65 536 nodes / 524 288 arcs
     "netgen_8_14a": ("netgen", 16384, 131072),
     "netgen_8_16a": ("netgen", 65536, 524288),
     "netgen_8_18a": ("netgen", 262144, 2097152),
@@ -53,6 +55,10 @@ def make_instance(workload: str, scale: int = 1):
     from network_flow_solver_amd import generators
 
     fam, n, m = WORKLOADS[workload]
+    if fam == "gridgen":
+        return generators.gridgen_style(n * scale, m, seed=1, name=f"{workload}(synthetic,x{scale})")
+    if fam == "goto":
+        return generators.goto_style(n * scale, m, seed=1, name=f"{workload}(synthetic,x{scale})")
     return generators.netgen_style(n * scale, m * scale, seed=1, name=f"{workload}(synthetic,x{scale})")
 
 
@@ -217,6 +223,15 @@ def main():
         except Exception as exc:  # measurement aid only
             line["hbm_point"]["measured_copy_GBps"] = None
             line["hbm_point"]["copy_error"] = str(exc)
+    if not args.no_hbm_point and workload == "netgen_8_08a":
+        # the other single-GPU-runnable BASELINE.json configs, measured the same way (no profiled pass)
+        pts = []
+        for wl, r, label in (("gridgen_8_14a", 1, "configs[2]: gridgen_8_14a, block-search Devex"),
+                             ("goto_8_16a", 0, "configs[3] shape on 1 GPU: goto_8_16a, full-scan Dantzig")):
+            m_ = measure_single(wl, 2000, 200, r, profile_pass=False)
+            pts.append({"config": label, "workload": m_["workload"], "pivots_per_sec": m_["pivots_per_sec"],
+                        "arcs_priced_per_sec": m_["arcs_priced_per_sec"], "ms_per_step": m_["ms_per_step"], "steps": m_["pivots"]})
+        line["config_points"] = pts
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(workload)
         if "hbm_point" in line:

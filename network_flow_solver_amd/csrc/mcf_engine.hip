@@ -424,15 +424,18 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     STAMP(0);
 
     McfCtx* c = v.ctx;
-    // per-bucket bounds of the block being priced, cached in LDS: mcf_bucket_slice costs four
-    // emulated 64-bit divisions, so it is re-evaluated (by 8 lanes) only when the block changes
-    __shared__ int64_t s_lo[MCF_NUM_BUCKETS], s_hi[MCF_NUM_BUCKETS];
-    __shared__ int64_t s_block;
-    if (threadIdx.x < MCF_NUM_BUCKETS) {
-        const int64_t nb0 = rule == MCF_RULE_DEVEX_BLOCK ? c->num_blocks : 1;
-        const int64_t kb0 = rule == MCF_RULE_DEVEX_BLOCK ? c->block_index : 0;
-        mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, kb0, nb0, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
-        if (threadIdx.x == 0) s_block = kb0;
+    // per-bucket bounds of every Devex block, tabulated in LDS once: mcf_bucket_slice costs four
+    // emulated 64-bit divisions, and the block advances after every pivot (up to kTabBlocks blocks;
+    // beyond that the bounds of the current block are recomputed by 8 lanes per pivot)
+    constexpr int kTabBlocks = 32;
+    __shared__ int64_t s_lo[kTabBlocks * MCF_NUM_BUCKETS], s_hi[kTabBlocks * MCF_NUM_BUCKETS];
+    const int64_t nb_all = rule == MCF_RULE_DEVEX_BLOCK ? c->num_blocks : 1;
+    const bool tabulated = nb_all <= kTabBlocks;
+    if (tabulated) {
+        for (int q = threadIdx.x; q < (int)nb_all * MCF_NUM_BUCKETS; q += kSmallThreads)
+            mcf_bucket_slice(g.bucket_off, q % MCF_NUM_BUCKETS, 0, 1, q / MCF_NUM_BUCKETS, nb_all, &s_lo[q], &s_hi[q]);
+    } else if (threadIdx.x < MCF_NUM_BUCKETS) {
+        mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, c->block_index, nb_all, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
     }
     __syncthreads();
     while (c->status == MCF_RUNNING) {
@@ -442,7 +445,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
             // 128 lanes per head bucket, all eight buckets at once
             constexpr int kPer = kSmallThreads / MCF_NUM_BUCKETS;
             const int x = threadIdx.x / kPer, l = threadIdx.x % kPer;
-            const int64_t lo = s_lo[x], hi = s_hi[x];
+            const int row = tabulated && rule == MCF_RULE_DEVEX_BLOCK ? (int)c->block_index * MCF_NUM_BUCKETS : 0;
+            const int64_t lo = s_lo[row + x], hi = s_hi[row + x];
             for (int64_t i = lo + l; i < hi; i += kPer) {
                 if (!v.state[i]) continue;
                 const int64_t viol = mcf_violation(v, i);
@@ -462,8 +466,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         // ---- pivot: one lane, everything it touches is in LDS
         if (threadIdx.x == 0) {
             if (c->pivots < c->max_pivots) {
+                const int row = tabulated && rule == MCF_RULE_DEVEX_BLOCK ? (int)c->block_index * MCF_NUM_BUCKETS : 0;
                 int64_t priced = 0;
-                for (int x = 0; x < MCF_NUM_BUCKETS; ++x) priced += s_hi[x] - s_lo[x];
+                for (int x = 0; x < MCF_NUM_BUCKETS; ++x) priced += s_hi[row + x] - s_lo[row + x];
                 c->arcs_priced += priced;
             }
             mcf_pivot_walk(v, key, arc, rule);
@@ -484,11 +489,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         }
         __syncthreads();
         if (threadIdx.x == 0) c->apply = 0;
-        if (rule == MCF_RULE_DEVEX_BLOCK && threadIdx.x < MCF_NUM_BUCKETS && s_block != c->block_index)
-            mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, c->block_index, c->num_blocks, &s_lo[threadIdx.x],
-                             &s_hi[threadIdx.x]);
+        if (!tabulated && threadIdx.x < MCF_NUM_BUCKETS)
+            mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, c->block_index, nb_all, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
         __syncthreads();
-        if (threadIdx.x == 0) s_block = c->block_index;
         STAMP(5);
     }
 

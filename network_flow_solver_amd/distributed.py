@@ -173,7 +173,12 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
     def measure(wl: str, steps: int, warmup: int) -> dict:
         fam, n1, m1 = workloads[wl]
         # weak scaling: per-GPU arcs fixed, the instance grows with the number of GPUs
-        inst = generators.netgen_style(n1 * world, m1 * world, seed=1, name=f"{wl}(synthetic,x{world})")
+        if fam == "gridgen":
+            inst = generators.gridgen_style(n1 * world, m1, seed=1, name=f"{wl}(synthetic,x{world})")
+        elif fam == "goto":
+            inst = generators.goto_style(n1 * world, m1, seed=1, name=f"{wl}(synthetic,x{world})")
+        else:
+            inst = generators.netgen_style(n1 * world, m1 * world, seed=1, name=f"{wl}(synthetic,x{world})")
         eng = HipShardEngine(inst, rule, rank, world, local_rank)
         force = os.environ.get("MCF_BENCH_FORCE_DIST") == "1"  # 1-GPU rehearsal: still issue the collective
         loop = PivotLoop(eng, dist, world, batch=32, always_gather=force,
