@@ -118,7 +118,7 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9
         out["kernel_ms"] = {"price": price_ms, "pivot": pivot_ms, "apply": apply_ms, "price_back_to_back": sweep_ms}
         mode = p1.get("pricing_mode", 0)
-        kname = ("k_price_rc" if mode == 1 else "k_price") + ("<dantzig>" if rule == 0 else "<devex_block>")
+        kname = ("k_price_rc" if mode == 1 else "k_price") + ("<devex_block>" if rule == 1 else "<dantzig>")
         out["pricing_mode"] = {0: "gather sweep", 1: "resident reduced costs", 2: "fused LDS loop"}.get(mode, str(mode))
         traffic, traffic_src = None, None
         try:  # PMC traffic is collected offline (rocprofv3 --pmc passes) and committed under profiles/
@@ -178,11 +178,11 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
-    ap.add_argument("--rule", default="dantzig", choices=["dantzig", "devex"])
+    ap.add_argument("--rule", default="dantzig", choices=["dantzig", "devex", "candidate_list"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-point", action="store_true")
     args = ap.parse_args()
-    rule = 0 if args.rule == "dantzig" else 1
+    rule = {"dantzig": 0, "devex": 1, "candidate_list": 2}[args.rule]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("MCF_BENCH_FORCE_DIST") == "1":  # env: rehearse the sharded path on 1 GPU
@@ -201,7 +201,8 @@ def main():
         "value": head["arcs_priced_per_sec"], "unit": "arcs/s", "pivots_per_sec": head["pivots_per_sec"],
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": head["workload"], "pricing": "full-scan Dantzig" if rule == 0 else "block-search Devex",
+        "config": {"workload": head["workload"],
+                   "pricing": {0: "full-scan Dantzig", 1: "block-search Devex", 2: "candidate list"}[rule],
                    "step": "one pivot (price + ratio test + tree/potential update)", "parallelism": "1 GPU",
                    "restarts_in_timed_region": head["restarts"]},
         "roofline": head.get("roofline"), "kernel_ms": head.get("kernel_ms"),
@@ -227,7 +228,8 @@ def main():
         # the other single-GPU-runnable BASELINE.json configs, measured the same way (no profiled pass)
         pts = []
         for wl, r, label in (("gridgen_8_14a", 1, "configs[2]: gridgen_8_14a, block-search Devex"),
-                             ("goto_8_16a", 0, "configs[3] shape on 1 GPU: goto_8_16a, full-scan Dantzig")):
+                             ("goto_8_16a", 0, "configs[3] shape on 1 GPU: goto_8_16a, full-scan Dantzig"),
+                             ("netgen_1m_16m", 2, "configs[4] shape on 1 GPU, candidate-list rule (the reference's default family)")):
             m_ = measure_single(wl, 2000, 200, r, profile_pass=False)
             pts.append({"config": label, "workload": m_["workload"], "pivots_per_sec": m_["pivots_per_sec"],
                         "arcs_priced_per_sec": m_["arcs_priced_per_sec"], "ms_per_step": m_["ms_per_step"], "steps": m_["pivots"]})

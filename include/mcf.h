@@ -60,6 +60,8 @@ extern "C" {
 #define MCF_RULE_DANTZIG_FULL 0   /* full-scan most-violating arc (simplex_pricing.py:97-137) */
 #define MCF_RULE_DEVEX_BLOCK 1    /* round-robin block search, merit rc^2/w, deferred weight update
                                      (simplex_pricing.py:310-357, 271-292) */
+#define MCF_RULE_CANDIDATE_LIST 2 /* full Dantzig sweep keeps one candidate per pricing workgroup; the following
+                                     pivots re-price only that list (simplex_pricing.py:375-542, 419-456) */
 
 /* "uncapacitated" marker accepted in cap[] (besides any value >= 2^60) */
 #define MCF_CAP_INF (-1)

@@ -45,6 +45,13 @@ enum McfStatus : int32_t {
 #ifndef MCF_RULE_DEVEX_BLOCK
 #define MCF_RULE_DEVEX_BLOCK 1
 #endif
+// Candidate list (simplex_pricing.py:375-542): a full Dantzig sweep leaves one candidate per
+// pricing workgroup; the next `minor_cap` pivots only re-price that list ("minor iterations",
+// simplex_pricing.py:419-456) before the next full sweep.  Optimality is only ever declared by a
+// full sweep.
+#ifndef MCF_RULE_CANDIDATE_LIST
+#define MCF_RULE_CANDIDATE_LIST 2
+#endif
 
 // One 16-byte record per node: a cycle walk needs exactly one load per step.
 struct alignas(16) McfNode {
@@ -95,6 +102,11 @@ struct McfCtx {
     int64_t block_index;       // block the next pricing pass scans
     int32_t empty_blocks;      // consecutive blocks without a candidate
     int32_t num_blocks;
+    // ---- candidate-list state
+    int32_t minor_left;        // > 0: the next pass re-prices the candidate list instead of sweeping
+    int32_t minor_cap;         // minor pivots allowed per full sweep
+    int64_t minor_pivots;      // pivots taken from a re-priced list (diagnostic)
+    int64_t major_sweeps;      // full sweeps (diagnostic)
     // ---- preorder double buffer
     int32_t cur;               // which order[] copy is current
     int32_t pending_flip;      // the last apply wrote order[cur^1]; flip before the next pivot
@@ -172,6 +184,18 @@ MCF_HD int64_t mcf_violation(const McfView& v, int64_t i) {
     return -(int64_t)v.state[i] * rc;
 }
 
+// Candidate-list minor iteration: current violation of a listed arc (packed id), 0 when it is no
+// longer eligible.  Reads the resident reduced cost when there is one.
+MCF_HD int64_t mcf_minor_key(const McfView& v, int64_t packed_arc) {
+    if (packed_arc < 0) return 0;
+    const int64_t e = packed_arc & 0xffffffff;
+    const int64_t s = v.state[e];
+    if (s == 0) return 0;
+    const int64_t rc = v.rcache ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
+    const int64_t viol = -s * rc;
+    return viol > 0 ? viol : 0;
+}
+
 // ---------------------------------------------------------------------------
 // One pivot = mcf_pivot_walk (ONE lane) + mcf_pivot_finish (ALL lanes of the workgroup,
 // after a barrier).
@@ -196,8 +220,13 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     }
     if (c->pivots >= c->max_pivots) { c->status = MCF_PIVOT_LIMIT; return; }
 
+    const bool minor = rule == MCF_RULE_CANDIDATE_LIST && c->minor_left > 0;
+    if (rule == MCF_RULE_CANDIDATE_LIST && !minor) c->major_sweeps += 1;
     if (best_arc < 0 || best_key <= 0) {
-        if (rule == MCF_RULE_DEVEX_BLOCK) {
+        if (minor) {
+            // the list is exhausted, which says nothing about optimality: sweep again next pass
+            c->minor_left = 0;
+        } else if (rule == MCF_RULE_DEVEX_BLOCK) {
             // this block held no eligible arc: move on (simplex_pricing.py:325-355)
             c->empty_blocks += 1;
             c->block_index += 1;
@@ -209,6 +238,10 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
         return;
     }
     c->empty_blocks = 0;
+    if (rule == MCF_RULE_CANDIDATE_LIST) {
+        if (minor) { c->minor_left -= 1; c->minor_pivots += 1; }
+        else c->minor_left = c->minor_cap;
+    }
     if (rule == MCF_RULE_DEVEX_BLOCK) {
         // Cyclic partial pricing: the next pass looks at the NEXT block whether or not this one had a
         // candidate.  The reference stays on a block until it is exhausted (simplex_pricing.py:325-355);

@@ -109,12 +109,15 @@ __global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shar
                                                           int64_t f_lo, int64_t f_hi, McfCand* __restrict__ cand) {
     int64_t key = 0, arc = -1;
     const McfCtx* c = v.ctx;
+    // candidate-list rule: while minor iterations are pending the list of the last sweep must
+    // survive, so the whole launch is a no-op (use_block == 2 marks that rule)
+    if (use_block == 2 && c->minor_left > 0 && c->status == MCF_RUNNING) return;
     if (c->status == MCF_RUNNING) {
         const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
         const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
         int64_t lo, hi;
-        mcf_bucket_slice(v.bucket_off, x, shard, shards, use_block ? c->block_index : 0, use_block ? c->num_blocks : 1,
-                         &lo, &hi);
+        mcf_bucket_slice(v.bucket_off, x, shard, shards, use_block == 1 ? c->block_index : 0,
+                         use_block == 1 ? c->num_blocks : 1, &lo, &hi);
         const int64_t g_lo = lo >> 2, g_hi = (hi + 3) >> 2;  // groups of 4 arcs
         const int4* __restrict__ tail4 = reinterpret_cast<const int4*>(v.tail);
         const int4* __restrict__ head4 = reinterpret_cast<const int4*>(v.head);
@@ -195,12 +198,15 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
                                                              int64_t f_lo, int64_t f_hi, McfCand* __restrict__ cand) {
     int64_t key = 0, arc = -1;
     const McfCtx* c = v.ctx;
+    // candidate-list rule: while minor iterations are pending the list of the last sweep must
+    // survive, so the whole launch is a no-op (use_block == 2 marks that rule)
+    if (use_block == 2 && c->minor_left > 0 && c->status == MCF_RUNNING) return;
     if (c->status == MCF_RUNNING) {
         const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
         const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
         int64_t lo, hi;
-        mcf_bucket_slice(v.bucket_off, x, shard, shards, use_block ? c->block_index : 0, use_block ? c->num_blocks : 1,
-                         &lo, &hi);
+        mcf_bucket_slice(v.bucket_off, x, shard, shards, use_block == 1 ? c->block_index : 0,
+                         use_block == 1 ? c->num_blocks : 1, &lo, &hi);
         const int64_t g_lo = lo >> 2, g_hi = (hi + 3) >> 2;  // groups of 4 arcs
         using rc2_t = long2;                                  // two int64 reduced costs per 16-byte load
         const rc2_t* __restrict__ rc2 = reinterpret_cast<const rc2_t*>(v.rcache);
@@ -307,16 +313,20 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView v, const McfCan
         return;
     }
     int64_t key = 0, arc = -1;
+    // candidate-list rule, minor iteration: no sweep ran; the listed arcs are re-priced here
+    // against the current state (resident reduced cost or potentials)
+    const bool minor = rule == MCF_RULE_CANDIDATE_LIST && v.ctx->minor_left > 0;
     for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
         const McfCand cd = cand[i];
-        if (mcf_cand_better(cd.key, cd.arc, key, arc)) { key = cd.key; arc = cd.arc; }
+        const int64_t kk = minor ? mcf_minor_key(v, cd.arc) : cd.key;
+        if (mcf_cand_better(kk, cd.arc, key, arc)) { key = kk; arc = cd.arc; }
     }
     block_argmax<kPivotThreads>(key, arc);
     if (threadIdx.x == 0) {
         McfCtx* c = v.ctx;
         if (c->pivots < c->max_pivots) {
             // whole-job accounting: the arcs of this pass over ALL shards
-            int64_t priced = v.m;  // full sweep: every arc (no 64-bit divisions on the hot path)
+            int64_t priced = minor ? ncand : v.m;  // full sweep: every arc (no 64-bit divisions on the hot path)
             if (rule == MCF_RULE_DEVEX_BLOCK && c->num_blocks > 1) {
                 priced = 0;
                 for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
@@ -379,7 +389,8 @@ __device__ __forceinline__ void copy_words(void* dst, const void* src, uint32_t 
 #define STAMP(slot) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallLayout L, int32_t rule) {
+__global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallLayout L, int32_t rule,
+                                                                McfCand* __restrict__ list) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef MCF_STAMPS
     unsigned long long stamps_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -438,10 +449,23 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, c->block_index, nb_all, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
     }
     __syncthreads();
-    while (c->status == MCF_RUNNING) {
+    // candidate-list rule: the list is the best arc of each head bucket (= of each of the 8 pricing
+    // workgroups the three-kernel path would use at this size); minor iterations re-price just
+    // those 8 arcs.  The list survives between launches in `list` (global).
+    const bool listing = rule == MCF_RULE_CANDIDATE_LIST;
+    __shared__ int64_t s_lk[MCF_NUM_BUCKETS], s_la[MCF_NUM_BUCKETS];
+    if (listing && threadIdx.x < MCF_NUM_BUCKETS) { s_lk[threadIdx.x] = list[threadIdx.x].key; s_la[threadIdx.x] = list[threadIdx.x].arc; }
+    __syncthreads();
+    for (;;) {
+        // uniform control values are read BEFORE a barrier: lane 0 rewrites them later in this very
+        // iteration (mcf_pivot_walk), and a lagging wave must not see the new values
+        const int32_t status_now = c->status;
+        const bool minor = listing && c->minor_left > 0;
+        __syncthreads();
+        if (status_now != MCF_RUNNING) break;
         // ---- price: the arc set of k_price for shard 0 of 1
         int64_t key = 0, arc = -1;
-        {
+        if (!minor) {
             // 128 lanes per head bucket, all eight buckets at once
             constexpr int kPer = kSmallThreads / MCF_NUM_BUCKETS;
             const int x = threadIdx.x / kPer, l = threadIdx.x % kPer;
@@ -461,15 +485,38 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
             }
         }
         STAMP(1);
-        block_argmax<kSmallThreads>(key, arc);
+        if (listing) {
+            __shared__ int64_t s_wk[kSmallThreads / 64], s_wa[kSmallThreads / 64];
+            if (!minor) {
+                wave_argmax(key, arc);
+                if ((threadIdx.x & 63) == 0) { s_wk[threadIdx.x >> 6] = key; s_wa[threadIdx.x >> 6] = arc; }
+                __syncthreads();
+                if (threadIdx.x < MCF_NUM_BUCKETS) {  // two waves per bucket
+                    const int w = 2 * threadIdx.x;
+                    const bool second = mcf_cand_better(s_wk[w + 1], s_wa[w + 1], s_wk[w], s_wa[w]);
+                    s_lk[threadIdx.x] = second ? s_wk[w + 1] : s_wk[w];
+                    s_la[threadIdx.x] = second ? s_wa[w + 1] : s_wa[w];
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                key = 0; arc = -1;
+                for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+                    const int64_t kk = minor ? mcf_minor_key(v, s_la[x]) : s_lk[x];
+                    if (mcf_cand_better(kk, s_la[x], key, arc)) { key = kk; arc = s_la[x]; }
+                }
+            }
+        } else {
+            block_argmax<kSmallThreads>(key, arc);
+        }
         STAMP(2);
-        // ---- pivot: one lane, everything it touches is in LDS
+        // ---- pivot: one lane walks, everything it touches is in LDS
         if (threadIdx.x == 0) {
             if (c->pivots < c->max_pivots) {
                 const int row = tabulated && rule == MCF_RULE_DEVEX_BLOCK ? (int)c->block_index * MCF_NUM_BUCKETS : 0;
                 int64_t priced = 0;
                 for (int x = 0; x < MCF_NUM_BUCKETS; ++x) priced += s_hi[row + x] - s_lo[row + x];
-                c->arcs_priced += priced;
+                c->arcs_priced += minor ? MCF_NUM_BUCKETS : priced;
             }
             mcf_pivot_walk(v, key, arc, rule);
         }
@@ -503,6 +550,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     copy_words(g.order[0], smem + L.order0, N * 4u);
     copy_words(g.order[1], smem + L.order1, N * 4u);
     copy_words(g.ctx, smem + L.ctx, (uint32_t)sizeof(McfCtx));
+    if (listing && threadIdx.x < MCF_NUM_BUCKETS) list[threadIdx.x] = McfCand{s_lk[threadIdx.x], s_la[threadIdx.x]};
 #ifdef MCF_STAMPS
     STAMP(6);
     if (threadIdx.x == 0) {  // diagnostic build only: cycle sums into the (global) path scratch, read by mcf_debug_stamps
@@ -546,6 +594,7 @@ struct mcf_handle {
     McfSeg* d_seg = nullptr;
     McfCtx* d_ctx = nullptr;
     McfCand* d_cand = nullptr;
+    McfCand* d_cand_aux = nullptr;  // scratch for mcf_price_once / mcf_time_pricing: the live list in d_cand must survive them
     McfCand* d_one = nullptr;
     McfCtx* h_ctx = nullptr;   // pinned
     McfCand* h_one = nullptr;  // pinned
@@ -615,6 +664,7 @@ int upload_image(mcf_handle* h) {
     c.block_size = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? bs : (m > 0 ? m : 1);
     c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
     if (c.num_blocks < 1) c.num_blocks = 1;
+    c.minor_cap = mcf_minor_cap(h->price_blocks);
     *h->h_ctx = c;
     HIP_TRY(h, hipMemcpyAsync(h->d_ctx, h->h_ctx, sizeof(McfCtx), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -634,19 +684,22 @@ int upload_image(mcf_handle* h) {
     return MCF_OK;
 }
 
-void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, int use_block) {
+void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, int use_block, McfCand* out = nullptr) {
+    if (!out) out = h->d_cand;
     const dim3 grid(h->price_blocks), block(kPriceThreads);
     const int64_t z = 0;
+    // use_block: 0 = whole shard, 1 = current Devex block, 2 = whole shard unless minor iterations are pending
+    if (rule == MCF_RULE_CANDIDATE_LIST && use_block) use_block = 2;
     if (h->rcached) {
         if (rule == MCF_RULE_DEVEX_BLOCK)
-            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, h->d_cand);
+            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out);
         else
-            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false>), grid, block, 0, s, v, h->shard, h->shards, 0, z, z, h->d_cand);
+            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out);
     } else {
         if (rule == MCF_RULE_DEVEX_BLOCK)
-            hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, h->d_cand);
+            hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out);
         else
-            hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, false>), grid, block, 0, s, v, h->shard, h->shards, 0, z, z, h->d_cand);
+            hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out);
     }
 }
 
@@ -657,7 +710,7 @@ void launch_apply(mcf_handle* h, hipStream_t s) {
 
 void launch_pivot_triplet(mcf_handle* h, hipStream_t s) {
     const int32_t rule = h->opt.rule;
-    launch_price(h, s, h->view, rule, rule == MCF_RULE_DEVEX_BLOCK);
+    launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG);
     hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, h->d_cand, h->price_blocks, rule);
     launch_apply(h, s);
 }
@@ -686,7 +739,7 @@ int run_batch_profiled(mcf_handle* h, int batch) {
     for (int i = 0; i < batch; ++i) {
         hipEvent_t* ev = &h->events[(size_t)i * 4];
         HIP_TRY(h, hipEventRecord(ev[0], h->stream));
-        launch_price(h, h->stream, h->view, rule, rule == MCF_RULE_DEVEX_BLOCK);
+        launch_price(h, h->stream, h->view, rule, rule != MCF_RULE_DANTZIG);
         HIP_TRY(h, hipEventRecord(ev[1], h->stream));
         hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, h->stream, h->view, h->d_cand, h->price_blocks, rule);
         HIP_TRY(h, hipEventRecord(ev[2], h->stream));
@@ -718,7 +771,7 @@ void free_all(mcf_handle* h) {
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
-    (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_one);
+    (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
     if (h->h_one) (void)hipHostFree(h->h_one);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -752,7 +805,10 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     mcf_options opt;
     if (opt_in) opt = *opt_in; else mcf_default_options(&opt);
     if (opt.abi_version != MCF_ABI_VERSION) { g_create_error = "mcf_options.abi_version mismatch"; return MCF_E_BAD_ARG; }
-    if (opt.rule != MCF_RULE_DANTZIG_FULL && opt.rule != MCF_RULE_DEVEX_BLOCK) { g_create_error = "unknown pricing rule"; return MCF_E_BAD_ARG; }
+    if (opt.rule != MCF_RULE_DANTZIG_FULL && opt.rule != MCF_RULE_DEVEX_BLOCK && opt.rule != MCF_RULE_CANDIDATE_LIST) {
+        g_create_error = "unknown pricing rule";
+        return MCF_E_BAD_ARG;
+    }
     const int ndev = usable_devices();
     if (ndev <= 0) { g_create_error = "no HIP device available (the engine has no CPU path)"; return MCF_E_NO_DEVICE; }
     mcf_handle* h = new (std::nothrow) mcf_handle();
@@ -777,13 +833,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     }
     const McfHostImage& im = h->im;
     {
-        // 256 lanes x 4 arcs per workgroup pass; a multiple of 8 workgroups so every XCD bucket is covered
-        const int64_t per_pass = (int64_t)kPriceThreads * 4 * kUnroll;
-        const int64_t per_bucket = (m / h->shards / MCF_NUM_BUCKETS + per_pass - 1) / per_pass;
-        int64_t pb = opt.price_blocks > 0 ? (opt.price_blocks + 7) / 8 : per_bucket;
-        if (pb < 1) pb = 1;
-        if (pb > kMaxPriceBlocks / MCF_NUM_BUCKETS) pb = kMaxPriceBlocks / MCF_NUM_BUCKETS;
-        h->price_blocks = (int)pb * MCF_NUM_BUCKETS;
+        // 8 * k workgroups, one group of k per XCD head bucket (formula shared with the CPU emulation)
+        h->price_blocks = mcf_price_blocks(m, h->shards, opt.price_blocks);
         const int64_t ab = ((int64_t)im.n_nodes + kApplyThreads - 1) / kApplyThreads;
         h->apply_blocks = (int)(ab < kMaxApplyBlocks ? ab : kMaxApplyBlocks);
     }
@@ -815,6 +866,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     if ((e = dalloc(&h->d_seg, 2 * N + 2)) != hipSuccess) return fail("hipMalloc seg", e);
     if ((e = dalloc(&h->d_ctx, 1)) != hipSuccess) return fail("hipMalloc ctx", e);
     if ((e = dalloc(&h->d_cand, kMaxPriceBlocks)) != hipSuccess) return fail("hipMalloc cand", e);
+    if ((e = dalloc(&h->d_cand_aux, kMaxPriceBlocks)) != hipSuccess) return fail("hipMalloc cand", e);
+    if ((e = hipMemset(h->d_cand, 0xff, kMaxPriceBlocks * sizeof(McfCand))) != hipSuccess) return fail("hipMemset cand", e);
     if ((e = dalloc(&h->d_one, 1)) != hipSuccess) return fail("hipMalloc one", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_ctx), sizeof(McfCtx), hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_one), sizeof(McfCand), hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
@@ -917,7 +970,7 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
         for (;;) {
             if (h->small)
                 hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(kSmallThreads), h->small_layout.total, h->stream, h->view,
-                                   h->small_layout, h->opt.rule);
+                                   h->small_layout, h->opt.rule, h->d_cand);
             else if (h->opt.profile) { rc = run_batch_profiled(h, batch); if (rc) return rc; }
             else if (graph) HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
             else for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream);
@@ -1010,6 +1063,7 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
 
 int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int64_t* arc, int32_t* dir, int64_t* key) {
     if (!h || !arc) return MCF_E_BAD_ARG;
+    if (rule == MCF_RULE_CANDIDATE_LIST) rule = MCF_RULE_DANTZIG_FULL;  // the list is built by a Dantzig sweep
     if (rule != MCF_RULE_DANTZIG_FULL && rule != MCF_RULE_DEVEX_BLOCK) return MCF_E_BAD_ARG;
     if (start < 0 || end > h->im.m || start > end) { h->err = "mcf_price_once: bad range"; return MCF_E_BAD_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1027,17 +1081,17 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
         const int64_t z = 0, one = 1;
         if (h->rcached) {
             if (rule == MCF_RULE_DEVEX_BLOCK)
-                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand);
+                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux);
             else
-                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand);
+                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux);
         } else {
             if (rule == MCF_RULE_DEVEX_BLOCK)
-                hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand);
+                hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux);
             else
-                hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand);
+                hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux);
         }
     }
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, h->stream, h->d_cand, h->price_blocks, h->d_one);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, h->stream, h->d_cand_aux, h->price_blocks, h->d_one);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &saved, 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_one, h->d_one, sizeof(McfCand), hipMemcpyDeviceToHost, h->stream));
@@ -1060,7 +1114,7 @@ int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev) {
     if (!h || !cand_out_dev) return MCF_E_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int32_t rule = h->opt.rule;
-    launch_price(h, s, h->view, rule, rule == MCF_RULE_DEVEX_BLOCK);
+    launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG);
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, s, h->d_cand, h->price_blocks,
                        reinterpret_cast<McfCand*>(cand_out_dev));
     HIP_TRY(h, hipGetLastError());
@@ -1105,7 +1159,7 @@ int mcf_time_pricing(mcf_handle* h, int32_t rule, int32_t reps, double* ms_per_l
     hipEvent_t e0, e1;
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
-    auto once = [&]() { launch_price(h, h->stream, v, rule, rule == MCF_RULE_DEVEX_BLOCK); };
+    auto once = [&]() { launch_price(h, h->stream, v, rule == MCF_RULE_CANDIDATE_LIST ? MCF_RULE_DANTZIG : rule, rule == MCF_RULE_DEVEX_BLOCK, h->d_cand_aux); };
     once();  // warm
     HIP_TRY(h, hipEventRecord(e0, h->stream));
     for (int i = 0; i < reps; ++i) once();

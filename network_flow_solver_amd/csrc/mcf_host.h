@@ -165,6 +165,26 @@ inline void mcf_build_rcache(McfHostImage& im) {
     }
 }
 
+// Pricing grid: 8 * k workgroups (one group of k per XCD head bucket).  Shared with the CPU
+// emulation because the candidate-list rule keeps ONE candidate per pricing workgroup, so the
+// arc -> workgroup map ((group - first group of the slice) / 256 mod k, see k_price) is part of
+// the rule's definition.
+inline int mcf_price_blocks(int64_t m, int64_t shards, int requested) {
+    const int64_t per_pass = 256 * 4 * 2;  // lanes x arcs per group x groups in flight (sizing only)
+    int64_t pb = requested > 0 ? (requested + 7) / 8 : (m / (shards > 0 ? shards : 1) / MCF_NUM_BUCKETS + per_pass - 1) / per_pass;
+    if (pb < 1) pb = 1;
+    if (pb > 2048 / MCF_NUM_BUCKETS) pb = 2048 / MCF_NUM_BUCKETS;
+    return (int)pb * MCF_NUM_BUCKETS;
+}
+
+// minor pivots per full sweep for the candidate-list rule: the list has one entry per workgroup
+inline int mcf_minor_cap(int price_blocks) {
+    int r = price_blocks / 8;
+    if (r < 3) r = 3;       // the reference's minor_iterations_per_candidate (simplex_pricing.py:400)
+    if (r > 32) r = 32;
+    return r;
+}
+
 struct McfHostResult {
     int32_t status = 0;        // MCF_ST_* numbering of include/mcf.h
     __int128 objective = 0;

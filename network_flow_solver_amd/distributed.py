@@ -167,7 +167,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    rule = 0 if args.rule == "dantzig" else 1
+    rule = {"dantzig": 0, "devex": 1, "candidate_list": 2}[args.rule]
     workload = args.workload or "netgen_8_08a"
 
     def measure(wl: str, steps: int, warmup: int) -> dict:
@@ -215,7 +215,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         "value": head["arcs_priced_per_sec"], "unit": "arcs/s", "pivots_per_sec": head["pivots_per_sec"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": head["workload"], "pricing": "full-scan Dantzig" if rule == 0 else "block-search Devex",
+        "config": {"workload": head["workload"], "pricing": {0: "full-scan Dantzig", 1: "block-search Devex", 2: "candidate list"}[rule],
                    "step": "one pivot (sharded price + 16 B all-gather + replicated tree/potential update)",
                    "parallelism": f"arc-sharded x{world}, replicated tree, 1 RCCL all-gather per pivot",
                    "pivot_loop": head["pivot_loop"], "graph_error": head["graph_error"]},

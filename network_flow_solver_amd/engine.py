@@ -21,6 +21,7 @@ LIB_PATH = Path(os.environ.get("MCF_HIP_LIB", _PKG / "libmcf_hip.so"))  # overri
 
 RULE_DANTZIG = 0
 RULE_DEVEX_BLOCK = 1
+RULE_CANDIDATE_LIST = 2
 STATUS_NAMES = {0: "optimal", 1: "infeasible", 2: "iteration_limit", 3: "unbounded"}
 CAP_INF = -1
 

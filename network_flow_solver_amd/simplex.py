@@ -117,10 +117,11 @@ class NetworkSimplex:
 
     Same construction and ``solve`` contract as the reference class
     (simplex.py:62-265, :1446-1765).  ``SolverOptions.pricing_strategy``:
-    ``"dantzig"`` selects the full-scan pricing kernel; ``"devex"``, ``"candidate_list"`` and
-    ``"adaptive"`` select the block-search Devex kernel (the reference's candidate-list /
-    adaptive rules are host-side heuristics around the same reduced-cost sweep; the optimum
-    they reach is the same).
+    ``"dantzig"`` selects the full-scan pricing kernel, ``"devex"`` the block-search Devex
+    kernel, ``"candidate_list"`` and ``"adaptive"`` (which the reference starts as a candidate
+    list, simplex_pricing.py:545-587) the candidate-list rule: a full sweep keeps one candidate
+    per pricing workgroup and the following pivots re-price only that list.  All rules reach the
+    same optimum.
     """
 
     ROOT_NODE = "__network_simplex_root__"
@@ -136,7 +137,8 @@ class NetworkSimplex:
         self.actual_arc_count = len(self.flat.keys)
         self.degenerate_pivots = 0
         strategy = self._select_pricing_strategy()
-        self.pricing_rule = _engine.RULE_DANTZIG if strategy == "dantzig" else _engine.RULE_DEVEX_BLOCK
+        self.pricing_rule = {"dantzig": _engine.RULE_DANTZIG, "devex": _engine.RULE_DEVEX_BLOCK}.get(
+            strategy, _engine.RULE_CANDIDATE_LIST)  # candidate_list and adaptive (which starts as one)
         bs = self.options.block_size
         block_size = 0 if bs is None or isinstance(bs, str) else int(bs)
         self.engine = _engine.McfEngine(

@@ -312,7 +312,7 @@ def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int 
     flow = np.zeros(max(m, 1), np.int64)
     pot = np.zeros(n, np.int64)
     in_tree = np.zeros(max(m, 1), np.int8)
-    stats = np.zeros(10, np.int64)
+    stats = np.zeros(12, np.int64)
     parent, pred, size, pos, order = (np.zeros(n + 1, np.int32) for _ in range(5))
     tr = np.full(max(trace, 1), -2, np.int64)
     rc = lib.emul_solve(
@@ -330,7 +330,7 @@ def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int 
         "in_tree": in_tree[:m], "pivots": int(stats[0]), "degenerate": int(stats[1]), "bound_flips": int(stats[2]),
         "arcs_priced": int(stats[3]), "nodes_moved": int(stats[4]), "subtree_nodes": int(stats[5]),
         "cycle_arcs": int(stats[6]), "unbounded_arc": int(stats[7]), "artificial_flow": int(stats[8]),
-        "seconds": stats[9] / 1e9, "parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order,
+        "seconds": stats[9] / 1e9, "minor_pivots": int(stats[10]), "major_sweeps": int(stats[11]), "parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order,
         "trace": tr[:trace] if trace else None,
     }
 

@@ -26,6 +26,8 @@ struct Emul {
     McfCtx ctx;
     McfView view;
     int rule = 0;
+    int price_blocks = 8;
+    std::vector<McfCand> cand;  // candidate-list rule: one entry per (virtual) pricing workgroup
 };
 
 void bind(Emul& e) {
@@ -66,16 +68,21 @@ void bind(Emul& e) {
 
 // scalar stand-in for the pricing kernel: shard r of G, Devex block = ctx.block_index of
 // ctx.num_blocks (Dantzig: the single block 0 of 1); same arc set as k_price, same tie rule.
-// Returns the number of arcs looked at.
-int64_t price(const Emul& e, int64_t r, int64_t G, int64_t* key, int64_t* arc) {
+// For the candidate-list rule it also fills e.cand[] with the best arc of every (virtual) pricing
+// workgroup, using the kernel's arc -> workgroup map.  Returns the number of arcs looked at.
+int64_t price(Emul& e, int64_t r, int64_t G, int64_t* key, int64_t* arc) {
     const McfView& v = e.view;
     const int64_t nb = e.rule == MCF_RULE_DEVEX_BLOCK ? v.ctx->num_blocks : 1;
     const int64_t k = e.rule == MCF_RULE_DEVEX_BLOCK ? v.ctx->block_index : 0;
+    const bool listing = e.rule == MCF_RULE_CANDIDATE_LIST;
+    const int64_t nlb = e.price_blocks / MCF_NUM_BUCKETS;
+    if (listing) e.cand.assign(e.price_blocks, McfCand{0, -1});
     int64_t bk = 0, ba = -1, priced = 0;
     for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
         int64_t lo, hi;
         mcf_bucket_slice(v.bucket_off, x, r, G, k, nb, &lo, &hi);
         priced += hi - lo;
+        const int64_t g_lo = lo >> 2;
         for (int64_t i = lo; i < hi; ++i) {
             if (!v.state[i]) continue;
             const int64_t viol = mcf_violation(v, i);
@@ -87,11 +94,27 @@ int64_t price(const Emul& e, int64_t r, int64_t G, int64_t* key, int64_t* arc) {
             }
             const int64_t id = mcf_pack_arc(v.orig[i], i);
             if (mcf_cand_better(kk, id, bk, ba)) { bk = kk; ba = id; }
+            if (listing) {
+                McfCand& c = e.cand[(((i >> 2) - g_lo) >> 8) % nlb * MCF_NUM_BUCKETS + x];
+                if (mcf_cand_better(kk, id, c.key, c.arc)) { c.key = kk; c.arc = id; }
+            }
         }
     }
     *key = bk;
     *arc = ba;
     return priced;
+}
+
+// candidate-list minor iteration: re-price the listed arcs only
+int64_t price_minor(Emul& e, const McfCand* cands, int64_t ncand, int64_t* key, int64_t* arc) {
+    int64_t bk = 0, ba = -1;
+    for (int64_t i = 0; i < ncand; ++i) {
+        const int64_t kk = mcf_minor_key(e.view, cands[i].arc);
+        if (mcf_cand_better(kk, cands[i].arc, bk, ba)) { bk = kk; ba = cands[i].arc; }
+    }
+    *key = bk;
+    *arc = ba;
+    return ncand;
 }
 
 void init_blocks(Emul& e, int64_t block_size) {
@@ -102,6 +125,8 @@ void init_blocks(Emul& e, int64_t block_size) {
     c.block_size = e.rule == MCF_RULE_DEVEX_BLOCK ? block_size : (m > 0 ? m : 1);
     c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
     if (c.num_blocks < 1) c.num_blocks = 1;
+    e.price_blocks = mcf_price_blocks(m, 1, 0);
+    c.minor_cap = mcf_minor_cap(e.price_blocks);
 }
 
 }  // namespace
@@ -112,7 +137,7 @@ extern "C" {
 int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, const int64_t* cost,
                const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int64_t max_pivots,
                int32_t* status, int64_t* objective_hi_lo, int64_t* flow, int64_t* potential, int8_t* in_tree,
-               int64_t* stats /*[10]*/, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
+               int64_t* stats /*[12]*/, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
                int32_t* order, int64_t* trace_arcs, int64_t trace_cap, int32_t bucketed) {
     Emul e;
     e.rule = rule;
@@ -127,7 +152,9 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     int64_t ntrace = 0;
     while (c.status == MCF_RUNNING) {
         int64_t key, arc;
-        const int64_t priced = price(e, 0, 1, &key, &arc);
+        const bool minor = rule == MCF_RULE_CANDIDATE_LIST && c.minor_left > 0;
+        const int64_t priced = minor ? price_minor(e, e.cand.data(), (int64_t)e.cand.size(), &key, &arc)
+                                     : price(e, 0, 1, &key, &arc);
         if (c.pivots < c.max_pivots) c.arcs_priced += priced;
         if (trace_arcs && ntrace < trace_cap) trace_arcs[ntrace++] = arc < 0 ? -1 : (arc >> 32);
         mcf_pivot_seq(e.view, key, arc, rule);
@@ -156,6 +183,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     stats[4] = c.nodes_moved; stats[5] = c.subtree_nodes; stats[6] = c.cycle_arcs;
     stats[7] = c.unbounded_arc >= 0 ? e.im.orig[c.unbounded_arc] : -1;
     stats[8] = r.artificial_flow; stats[9] = (int64_t)(secs * 1e9);
+    stats[10] = c.minor_pivots; stats[11] = c.major_sweeps;
     const int32_t* ord = e.view.order[c.cur];
     for (int32_t v = 0; v <= n; ++v) {
         if (parent) parent[v] = e.im.node[v].parent;
@@ -187,9 +215,12 @@ void* emul_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head
     return e;
 }
 
-// best candidate of shard `r` of `G` (and of the current Devex block)
+// best candidate of shard `r` of `G` (and of the current Devex block).  Candidate-list rule: while
+// minor iterations are pending the pricing launch is a no-op and key_arc keeps the last sweep's
+// entry (exactly what the skipped k_price + k_reduce leave behind on the GPU).
 void emul_price(void* h, int64_t r, int64_t G, int64_t* key_arc /*[2]*/) {
     Emul* e = static_cast<Emul*>(h);
+    if (e->rule == MCF_RULE_CANDIDATE_LIST && e->ctx.minor_left > 0 && e->ctx.status == MCF_RUNNING) return;
     key_arc[0] = 0; key_arc[1] = -1;
     if (e->ctx.status == MCF_RUNNING) price(*e, r, G, &key_arc[0], &key_arc[1]);
 }
@@ -199,9 +230,12 @@ void emul_pivot(void* h, const int64_t* cands, int32_t ncand) {
     Emul* e = static_cast<Emul*>(h);
     McfCtx& c = e->ctx;
     if (c.status != MCF_RUNNING) return;
+    const bool minor = e->rule == MCF_RULE_CANDIDATE_LIST && c.minor_left > 0;
     int64_t key = 0, arc = -1;
-    for (int32_t i = 0; i < ncand; ++i)
-        if (mcf_cand_better(cands[2 * i], cands[2 * i + 1], key, arc)) { key = cands[2 * i]; arc = cands[2 * i + 1]; }
+    for (int32_t i = 0; i < ncand; ++i) {
+        const int64_t kk = minor ? mcf_minor_key(e->view, cands[2 * i + 1]) : cands[2 * i];
+        if (mcf_cand_better(kk, cands[2 * i + 1], key, arc)) { key = kk; arc = cands[2 * i + 1]; }
+    }
     mcf_pivot_seq(e->view, key, arc, e->rule);
     if (c.apply) {
         for (int32_t j = c.lo; j < c.hi; ++j) mcf_apply_one(e->view, c, j);

@@ -85,7 +85,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,rule,idx", [(2, 0, 0), (2, 1, 0), (3, 0, 3), (2, 1, 5)])
+@pytest.mark.parametrize("world,rule,idx", [(2, 0, 0), (2, 1, 0), (3, 0, 3), (2, 1, 5), (2, 2, 3)])
 def test_sharded_replicas_match_single_process(world, rule, idx):
     import oracle
 
@@ -103,6 +103,11 @@ def test_sharded_replicas_match_single_process(world, rule, idx):
         assert p.exitcode == 0
     for rank, status, pivots, objective, flow in results:
         assert status == 0                                   # optimal
-        assert pivots == single["pivots"]                    # same pivot sequence as one process
         assert objective == single["objective"]
-        assert np.array_equal(np.array(flow), single["flow"])
+        if rule != 2:
+            assert pivots == single["pivots"]                # same pivot sequence as one process
+            assert np.array_equal(np.array(flow), single["flow"])
+        else:
+            # candidate list: sharded, the list is the gathered per-rank bests (one entry per rank), so the
+            # pivot sequence depends on the rank count; the replicas must still agree with each other
+            assert pivots == results[0][2] and flow == results[0][4]

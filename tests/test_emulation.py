@@ -10,7 +10,7 @@ from conftest import check_optimality, check_tree_invariants, golden_flows, load
 
 
 @pytest.mark.parametrize("entry,inst", load_synthetic(), ids=lambda x: x["name"] if isinstance(x, dict) else "")
-@pytest.mark.parametrize("rule", [0, 1], ids=["dantzig", "devex_block"])
+@pytest.mark.parametrize("rule", [0, 1, 2], ids=["dantzig", "devex_block", "candidate_list"])
 def test_integer_engine_reaches_reference_optimum(entry, inst, rule):
     exp = next(iter(entry["expected"].values()))
     res = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
@@ -57,3 +57,15 @@ def test_pivot_budget_reports_iteration_limit():
     _, inst = load_synthetic()[0]
     r = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0, max_pivots=5)
     assert r["status"] == "iteration_limit" and r["pivots"] == 5
+
+
+def test_candidate_list_sweeps_far_less_than_dantzig():
+    """simplex_pricing.py:375-542 in engine form: same optimum, about the same number of pivots,
+    a fraction of the full sweeps (most pivots come from re-pricing the list)."""
+    _, inst = load_synthetic()[7]
+    d = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0)
+    c = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2)
+    assert c["objective"] == d["objective"] and c["status"] == "optimal"
+    assert c["major_sweeps"] + c["minor_pivots"] >= c["pivots"] and c["minor_pivots"] > c["pivots"] // 2
+    assert c["major_sweeps"] < d["pivots"] // 2 and c["arcs_priced"] < d["arcs_priced"] // 2
+    assert c["pivots"] < 1.3 * d["pivots"]

@@ -20,8 +20,8 @@ from network_flow_solver_amd import generators
 
 pytestmark = pytest.mark.gpu
 
-RULES = [0, 1]
-RULE_IDS = ["dantzig", "devex_block"]
+RULES = [0, 1, 2]
+RULE_IDS = ["dantzig", "devex_block", "candidate_list"]
 
 
 def _solve(engine, inst, rule, **kw):
@@ -96,7 +96,7 @@ def test_resident_reduced_costs_stay_exact(gpu_engine_module, rule):
 
 # ------------------------------------------------------------------ golden fixtures, through the reference-shaped API
 @pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
-@pytest.mark.parametrize("strategy", ["dantzig", "devex", "adaptive"])
+@pytest.mark.parametrize("strategy", ["dantzig", "devex", "adaptive", "candidate_list"])
 def test_small_cases_through_the_shim(gpu_engine_module, case, strategy):
     exp = case["expected"]["dantzig" if strategy == "dantzig" else "devex"]
     problem = nfs.build_problem(case["nodes"], case["arcs"], case["directed"], case["tolerance"])
@@ -248,6 +248,28 @@ def test_devex_merit_kernel(gpu_engine_module):
         # weights are >= 1 and only the selected arcs' weights changed: merit <= viol^2, and the
         # winner's merit is at least the best unit-weight merit of any arc never selected so far
         assert 0 < merit <= viol[got[0]] ** 2
+
+
+@pytest.mark.parametrize("idx", [3, 7], ids=["fused_lds_path", "kernel_path"])
+def test_candidate_list_survives_budget_and_resume(gpu_engine_module, idx):
+    """The candidate list lives on the device between solve() calls (and is not clobbered by the
+    re-pricing at a budget limit or by mcf_price_once), so a solve cut into pieces takes the very
+    same pivots as an uninterrupted one."""
+    _, inst = load_synthetic()[idx]
+    e = gpu_engine_module
+    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2) as eng:
+        eng.solve()
+        whole = eng.result()
+    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2) as eng:
+        for budget in (1, 1, 3, 10, 57):
+            eng.solve(max_pivots=budget)
+            eng.price_once(0)
+        eng.solve()
+        pieces = eng.result()
+    assert whole.status == pieces.status == "optimal"
+    assert pieces.stats["pivots"] == whole.stats["pivots"] and np.array_equal(pieces.flow, whole.flow)
+    em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2)
+    assert whole.stats["pivots"] == em["pivots"] and whole.stats["arcs_priced"] == em["arcs_priced"]
 
 
 # ------------------------------------------------------------------ solve-control edge cases
