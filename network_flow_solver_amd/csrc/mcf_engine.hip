@@ -111,7 +111,8 @@ __global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shar
     const McfCtx* c = v.ctx;
     // candidate-list rule: while minor iterations are pending the list of the last sweep must
     // survive, so the whole launch is a no-op (use_block == 2 marks that rule)
-    if (use_block == 2 && c->minor_left > 0 && c->status == MCF_RUNNING) return;
+    if (use_block == 2 && (c->minor_left > 0 || c->status != MCF_RUNNING)) return;  // (also: a finished batch's
+    // trailing launches must not wipe the list a resumed solve will want)
     if (c->status == MCF_RUNNING) {
         const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
         const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
     const McfCtx* c = v.ctx;
     // candidate-list rule: while minor iterations are pending the list of the last sweep must
     // survive, so the whole launch is a no-op (use_block == 2 marks that rule)
-    if (use_block == 2 && c->minor_left > 0 && c->status == MCF_RUNNING) return;
+    if (use_block == 2 && (c->minor_left > 0 || c->status != MCF_RUNNING)) return;  // (also: a finished batch's
+    // trailing launches must not wipe the list a resumed solve will want)
     if (c->status == MCF_RUNNING) {
         const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
         const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
