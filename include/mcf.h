@@ -172,6 +172,16 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
  * Tests use it to check the invariant resident rc == cost + pi[tail] - pi[head]. */
 int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident);
 
+/* ---- native DIMACS "p min" reader (host only; replaces benchmarks/parsers/dimacs.py:105-286 for
+ * instances too large for one Python object per arc).  Two calls: mcf_dimacs_scan returns the
+ * counts, mcf_dimacs_load fills caller-allocated arrays (0-based node ids; cap -1 = uncapacitated,
+ * also for the reference's "-1" / "inf" / >= 1e15 conventions, dimacs.py:216-221; 4-field arc lines
+ * mean lower = 0, dimacs.py:202-207).  Integer data only: a non-integral token is an error.
+ * Return 0 or MCF_E_BAD_ARG with a message in err (may be NULL). */
+int mcf_dimacs_scan(const char* path, int64_t* n_nodes, int64_t* n_arcs, char* err, int32_t err_len);
+int mcf_dimacs_load(const char* path, int64_t n_nodes, int64_t n_arcs, int32_t* tail, int32_t* head,
+                    int64_t* lower, int64_t* cap, int64_t* cost, int64_t* supply, char* err, int32_t err_len);
+
 const char* mcf_last_error(mcf_handle* h); /* NULL handle: last create-time error of this thread */
 void mcf_destroy(mcf_handle* h);
 int mcf_abi_version(void);

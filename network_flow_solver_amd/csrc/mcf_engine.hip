@@ -23,8 +23,10 @@
 // MCF_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -1258,6 +1260,145 @@ int mcf_debug_stamps(mcf_handle* h, unsigned long long* out8) {
     return MCF_OK;
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------
+// native DIMACS reader (host code; benchmarks/parsers/dimacs.py:105-286 restated for flat arrays)
+// ---------------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+int dimacs_fail(char* err, int32_t err_len, const std::string& msg) {
+    if (err && err_len > 0) { std::snprintf(err, (size_t)err_len, "%s", msg.c_str()); }
+    return MCF_E_BAD_ARG;
+}
+
+// parse one integer token; "inf" and values >= 1e15 map to `inf_value` when allow_inf
+bool dimacs_int(const char*& p, int64_t* out, bool allow_inf, int64_t inf_value) {
+    while (*p == ' ' || *p == '\t') ++p;
+    if (allow_inf && (p[0] == 'i' || p[0] == 'I') && (p[1] == 'n' || p[1] == 'N') && (p[2] == 'f' || p[2] == 'F')) {
+        p += 3;
+        *out = inf_value;
+        return true;
+    }
+    char* end = nullptr;
+    errno = 0;
+    const long long v = std::strtoll(p, &end, 10);
+    if (end == p || errno) return false;
+    if (*end == '.' || *end == 'e' || *end == 'E') {  // "12.0" is fine, "12.5" is not integral
+        char* fend = nullptr;
+        const double d = std::strtod(p, &fend);
+        if (fend == p || d != (double)(long long)d) return false;
+        p = fend;
+        *out = allow_inf && d >= 1e15 ? inf_value : (int64_t)d;
+        return true;
+    }
+    p = end;
+    *out = allow_inf && v >= 1000000000000000LL ? inf_value : (int64_t)v;
+    return true;
+}
+
+template <typename OnProblem, typename OnNode, typename OnArc>
+int dimacs_walk(const char* path, char* err, int32_t err_len, OnProblem on_p, OnNode on_n, OnArc on_a) {
+    FILE* f = std::fopen(path, "r");
+    if (!f) return dimacs_fail(err, err_len, std::string("DIMACS file not found: ") + path);
+    std::vector<char> line(1 << 16);
+    int64_t line_no = 0;
+    bool seen_p = false;
+    int rc = 0;
+    while (rc == 0 && std::fgets(line.data(), (int)line.size(), f)) {
+        ++line_no;
+        const char* p = line.data();
+        while (*p == ' ' || *p == '\t') ++p;
+        if (*p == 0 || *p == '\n' || *p == '\r' || *p == 'c') continue;
+        const char kind = *p++;
+        const std::string where = "Line " + std::to_string(line_no) + ": ";
+        if (kind == 'p') {
+            if (seen_p) { rc = dimacs_fail(err, err_len, where + "Multiple problem descriptor lines found."); break; }
+            while (*p == ' ' || *p == '\t') ++p;
+            if (std::strncmp(p, "min", 3) != 0) { rc = dimacs_fail(err, err_len, where + "Only 'min' (minimum cost flow) problems supported."); break; }
+            p += 3;
+            int64_t n = 0, m = 0;
+            if (!dimacs_int(p, &n, false, 0) || !dimacs_int(p, &m, false, 0)) { rc = dimacs_fail(err, err_len, where + "Expected 'p min <nodes> <arcs>'."); break; }
+            if (n <= 0) { rc = dimacs_fail(err, err_len, where + "Number of nodes must be positive."); break; }
+            if (m < 0) { rc = dimacs_fail(err, err_len, where + "Number of arcs cannot be negative."); break; }
+            seen_p = true;
+            rc = on_p(n, m, where);
+        } else if (kind == 'n') {
+            if (!seen_p) { rc = dimacs_fail(err, err_len, where + "Node descriptor before problem descriptor."); break; }
+            int64_t id = 0, sup = 0;
+            if (!dimacs_int(p, &id, false, 0) || !dimacs_int(p, &sup, false, 0)) { rc = dimacs_fail(err, err_len, where + "Expected 'n <node_id> <supply>' with integer data."); break; }
+            rc = on_n(id, sup, where);
+        } else if (kind == 'a') {
+            if (!seen_p) { rc = dimacs_fail(err, err_len, where + "Arc descriptor before problem descriptor."); break; }
+            int64_t v[5];
+            int k = 0;
+            // tail head [lower] cap cost : the capacity token is the second-to-last one
+            const char* q = p;
+            int tokens = 0;
+            for (const char* t = p; *t;) {
+                while (*t == ' ' || *t == '\t') ++t;
+                if (*t == 0 || *t == '\n' || *t == '\r') break;
+                ++tokens;
+                while (*t && *t != ' ' && *t != '\t' && *t != '\n' && *t != '\r') ++t;
+            }
+            if (tokens != 4 && tokens != 5) { rc = dimacs_fail(err, err_len, where + "Invalid arc descriptor format."); break; }
+            bool ok = true;
+            for (k = 0; k < tokens && ok; ++k) ok = dimacs_int(q, &v[k], k == tokens - 2, -1);
+            if (!ok) { rc = dimacs_fail(err, err_len, where + "Failed to parse arc line (integer data expected)."); break; }
+            const int64_t lower = tokens == 5 ? v[2] : 0;
+            int64_t cap = v[tokens - 2];
+            if (cap < 0) cap = -1;
+            rc = on_a(v[0], v[1], lower, cap, v[tokens - 1], where);
+        } else {
+            rc = dimacs_fail(err, err_len, where + "Unknown line type '" + std::string(1, kind) + "'.");
+        }
+    }
+    std::fclose(f);
+    if (rc == 0 && !seen_p) rc = dimacs_fail(err, err_len, "No problem descriptor found. DIMACS file must contain a 'p min <nodes> <arcs>' line.");
+    return rc;
+}
+}  // namespace
+}  // extern "C++"
+
+int mcf_dimacs_scan(const char* path, int64_t* n_nodes, int64_t* n_arcs, char* err, int32_t err_len) {
+    if (!path || !n_nodes || !n_arcs) return MCF_E_BAD_ARG;
+    int64_t n = 0, m = 0, arcs = 0;
+    const int rc = dimacs_walk(
+        path, err, err_len, [&](int64_t nn, int64_t mm, const std::string&) { n = nn; m = mm; return 0; },
+        [&](int64_t, int64_t, const std::string&) { return 0; },
+        [&](int64_t, int64_t, int64_t, int64_t, int64_t, const std::string&) { ++arcs; return 0; });
+    if (rc) return rc;
+    if (arcs != m)
+        return dimacs_fail(err, err_len, "Arc count mismatch: problem descriptor specifies " + std::to_string(m) + " arcs, but " +
+                                             std::to_string(arcs) + " arc descriptors found.");
+    *n_nodes = n;
+    *n_arcs = m;
+    return MCF_OK;
+}
+
+int mcf_dimacs_load(const char* path, int64_t n_nodes, int64_t n_arcs, int32_t* tail, int32_t* head, int64_t* lower,
+                    int64_t* cap, int64_t* cost, int64_t* supply, char* err, int32_t err_len) {
+    if (!path || !supply || (n_arcs > 0 && (!tail || !head || !lower || !cap || !cost))) return MCF_E_BAD_ARG;
+    for (int64_t v = 0; v < n_nodes; ++v) supply[v] = 0;
+    int64_t i = 0;
+    return dimacs_walk(
+        path, err, err_len,
+        [&](int64_t nn, int64_t mm, const std::string& where) {
+            return (nn == n_nodes && mm == n_arcs) ? 0 : dimacs_fail(err, err_len, where + "counts differ from mcf_dimacs_scan");
+        },
+        [&](int64_t id, int64_t sup, const std::string& where) {
+            if (id < 1 || id > n_nodes) return dimacs_fail(err, err_len, where + "node id outside [1, " + std::to_string(n_nodes) + "]");
+            supply[id - 1] = sup;
+            return 0;
+        },
+        [&](int64_t t, int64_t h, int64_t lo, int64_t cp, int64_t c, const std::string& where) {
+            if (t < 1 || t > n_nodes || h < 1 || h > n_nodes)
+                return dimacs_fail(err, err_len, where + "Arc references node IDs outside the expected range [1, " + std::to_string(n_nodes) + "]");
+            if (i >= n_arcs) return dimacs_fail(err, err_len, where + "more arc descriptors than the problem line announces");
+            tail[i] = (int32_t)(t - 1); head[i] = (int32_t)(h - 1); lower[i] = lo; cap[i] = cp; cost[i] = c;
+            ++i;
+            return 0;
+        });
+}
 
 void mcf_destroy(mcf_handle* h) {
     if (!h) return;

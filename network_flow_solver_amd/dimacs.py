@@ -120,52 +120,17 @@ def parse_dimacs_file(file_path: str | Path) -> NetworkProblem:
 
 
 def parse_dimacs_soa(file_path: str | Path) -> ArcSoA:
-    """DIMACS text -> flat integer arrays (0-based ids), for instances too large for the
-    object model.  Integer data and zero lower bounds only (what netgen/gridgen/goto emit)."""
+    """DIMACS text -> flat integer arrays (0-based ids) through the library's native reader
+    (``mcf_dimacs_scan`` / ``mcf_dimacs_load``): no per-arc Python objects, so it scales to the
+    16 M-arc instances the object model cannot hold.
+    Integer data and zero lower bounds only -- what netgen / gridgen / goto emit; anything else
+    should go through ``parse_dimacs_file``."""
+    from . import engine
+
     path = Path(file_path)
     if not path.exists():
         raise FileNotFoundError(f"DIMACS file not found: {file_path}")
-    n = m = None
-    node_rows, arc_rows = [], []
-    with path.open("r", encoding="utf-8") as fh:
-        for line_no, line in enumerate(fh, start=1):
-            if not line or line[0] == "c" or line.isspace():
-                continue
-            k = line[0]
-            if k == "a":
-                arc_rows.append(line[2:])
-            elif k == "n":
-                node_rows.append(line[2:])
-            elif k == "p":
-                tok = line.split()
-                if len(tok) != 4 or tok[1] != "min":
-                    raise InvalidProblemError(f"Line {line_no}: Expected 'p min <nodes> <arcs>', got: {line.strip()}")
-                n, m = int(tok[2]), int(tok[3])
-            else:
-                raise InvalidProblemError(f"Line {line_no}: Unknown line type '{k}'.")
-    if n is None:
-        raise InvalidProblemError("No problem descriptor found. DIMACS file must contain a 'p min <nodes> <arcs>' line.")
-    if m != len(arc_rows):
-        raise InvalidProblemError(
-            f"Arc count mismatch: problem descriptor specifies {m} arcs, but {len(arc_rows)} arc descriptors found.")
-    arcs = np.loadtxt(arc_rows, dtype=np.float64, ndmin=2) if arc_rows else np.zeros((0, 5))
-    if arcs.shape[1] == 4:
-        arcs = np.insert(arcs, 2, 0.0, axis=1)
-    if arcs.shape[1] != 5:
-        raise InvalidProblemError("Invalid arc descriptor format.")
-    if np.any(arcs[:, 2] != 0):
+    n, tail, head, lower, cap, cost, supply = engine.dimacs_load(str(path))
+    if lower.any():
         raise InvalidProblemError("parse_dimacs_soa supports zero lower bounds only; use parse_dimacs_file.")
-    if np.any(arcs != np.round(arcs)):
-        raise InvalidProblemError("parse_dimacs_soa supports integer data only; use parse_dimacs_file.")
-    tail = arcs[:, 0].astype(np.int64) - 1
-    head = arcs[:, 1].astype(np.int64) - 1
-    if m and (tail.min() < 0 or head.min() < 0 or tail.max() >= n or head.max() >= n):
-        raise InvalidProblemError(f"Arc references node IDs outside the expected range [1, {n}]")
-    cap = arcs[:, 3].astype(np.int64)
-    cap[(arcs[:, 3] < 0) | (arcs[:, 3] >= 1e15)] = -1
-    supply = np.zeros(n, dtype=np.int64)
-    if node_rows:
-        nd = np.loadtxt(node_rows, dtype=np.float64, ndmin=2)
-        supply[nd[:, 0].astype(np.int64) - 1] = nd[:, 1].astype(np.int64)
-    return ArcSoA(n, tail.astype(np.int32), head.astype(np.int32), arcs[:, 4].astype(np.int64), cap, supply,
-                  name=path.name)
+    return ArcSoA(n, tail, head, cost, cap, supply, name=path.name)

@@ -29,7 +29,7 @@ CAP_INF = -1
 ABI_SYMBOLS = (
     "mcf_default_options", "mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset",
     "mcf_enqueue_price", "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing",
-    "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
+    "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_dimacs_scan", "mcf_dimacs_load", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
 )
 
 
@@ -105,13 +105,16 @@ def load_library():
     lib.mcf_time_copy.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     lib.mcf_get_tree.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i8p, i64p]
     lib.mcf_get_reduced_costs.argtypes = [vp, i64p, i32p]
+    lib.mcf_dimacs_scan.argtypes = [ctypes.c_char_p, i64p, i64p, ctypes.c_char_p, ctypes.c_int32]
+    lib.mcf_dimacs_load.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, i64p,
+                                    ctypes.c_char_p, ctypes.c_int32]
     lib.mcf_last_error.argtypes = [vp]
     lib.mcf_last_error.restype = ctypes.c_char_p
     lib.mcf_destroy.argtypes = [vp]
     lib.mcf_destroy.restype = None
     for name in ("mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_enqueue_price",
                  "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing", "mcf_time_copy",
-                 "mcf_get_tree", "mcf_get_reduced_costs"):
+                 "mcf_get_tree", "mcf_get_reduced_costs", "mcf_dimacs_scan", "mcf_dimacs_load"):
         getattr(lib, name).restype = ctypes.c_int
     if lib.mcf_abi_version() != 1:
         raise EngineUnavailableError("libmcf_hip.so ABI version mismatch")
@@ -307,3 +310,26 @@ def time_copy(nbytes: int, reps: int = 10, device: int = -1) -> float:
     if rc != 0:
         raise EngineError(rc, "mcf_time_copy failed")
     return float(ms.value)
+
+
+def dimacs_load(path: str):
+    """Native DIMACS reader (host code in libmcf_hip.so; no GPU needed).
+    Returns (n, tail, head, lower, cap, cost, supply) with 0-based int arrays."""
+    from .exceptions import InvalidProblemError
+
+    lib = load_library()
+    n, m = ctypes.c_int64(0), ctypes.c_int64(0)
+    err = ctypes.create_string_buffer(512)
+    bpath = str(path).encode()
+    if lib.mcf_dimacs_scan(bpath, ctypes.byref(n), ctypes.byref(m), err, 512) != 0:
+        raise InvalidProblemError(err.value.decode())
+    tail = np.zeros(max(m.value, 1), np.int32)
+    head = np.zeros(max(m.value, 1), np.int32)
+    lower, cap, cost = (np.zeros(max(m.value, 1), np.int64) for _ in range(3))
+    supply = np.zeros(n.value, np.int64)
+    if lib.mcf_dimacs_load(bpath, n.value, m.value, _p(tail, ctypes.c_int32), _p(head, ctypes.c_int32),
+                           _p(lower, ctypes.c_int64), _p(cap, ctypes.c_int64), _p(cost, ctypes.c_int64),
+                           _p(supply, ctypes.c_int64), err, 512) != 0:
+        raise InvalidProblemError(err.value.decode())
+    k = m.value
+    return n.value, tail[:k], head[:k], lower[:k], cap[:k], cost[:k], supply

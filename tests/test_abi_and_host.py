@@ -183,3 +183,40 @@ def test_solver_adapter_never_raises_and_reports_availability():
     assert isinstance(res, SolverResult)
     if not Mi355xAdapter.is_available():
         assert res.status == "error" and "EngineUnavailableError" in res.error_message   # loud, but not an exception
+
+
+def test_native_dimacs_reader_matches_object_parser(tmp_path):
+    """mcf_dimacs_scan / mcf_dimacs_load (C, host side of the library) against the reference-shaped
+    object parser on generator output and on the reference's three .min fixtures, plus the error cases."""
+    from network_flow_solver_amd import generators as g
+
+    inst = g.netgen_style(200, 1600, seed=5)
+    inst.cap[::7] = -1                                         # some uncapacitated arcs
+    path = tmp_path / "net.min"
+    g.write_dimacs(inst, path)
+    soa = nfs.parse_dimacs_soa(path)
+    assert soa.n == inst.n and np.array_equal(soa.tail, inst.tail) and np.array_equal(soa.head, inst.head)
+    assert np.array_equal(soa.cost, inst.cost) and np.array_equal(soa.cap, inst.cap) and np.array_equal(soa.supply, inst.supply)
+    obj = nfs.parse_dimacs_file(path)
+    assert len(obj.arcs) == soa.m and [a.capacity for a in obj.arcs[:8]] == [None if c < 0 else float(c) for c in soa.cap[:8]]
+    for c in CASES:
+        if "dimacs_text" in c:
+            f = tmp_path / (c["name"] + ".min")
+            f.write_text(c["dimacs_text"])
+            s2 = nfs.parse_dimacs_soa(f)
+            p2 = nfs.parse_dimacs_file(f)
+            assert s2.n == len(p2.nodes) and s2.m == len(p2.arcs)
+            assert [int(x) for x in s2.cost] == [int(a.cost) for a in p2.arcs]
+    variants = {"four.min": "p min 2 1\nn 1 1\nn 2 -1\na 1 2 5 7\n", "inf.min": "c x\np min 2 2\nn 1 1\nn 2 -1\na 1 2 0 inf 3\na 1 2 0 1e15 4\n"}
+    for name, text in variants.items():
+        (tmp_path / name).write_text(text)
+    four = nfs.parse_dimacs_soa(tmp_path / "four.min")
+    assert four.cap.tolist() == [5] and four.cost.tolist() == [7]
+    assert nfs.parse_dimacs_soa(tmp_path / "inf.min").cap.tolist() == [-1, -1]
+    bad = {"nop.min": "n 1 1\n", "max.min": "p max 2 1\n", "count.min": "p min 2 2\na 1 2 0 1 1\n",
+           "range.min": "p min 2 1\na 1 9 0 1 1\n", "kind.min": "p min 2 1\nx 1\n", "frac.min": "p min 2 1\na 1 2 0 1 1.5\n",
+           "lower.min": "p min 2 1\nn 1 1\nn 2 -1\na 1 2 1 5 7\n"}
+    for name, text in bad.items():
+        (tmp_path / name).write_text(text)
+        with pytest.raises(nfs.InvalidProblemError):
+            nfs.parse_dimacs_soa(tmp_path / name)
