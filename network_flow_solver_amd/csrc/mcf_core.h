@@ -154,6 +154,9 @@ struct McfView {
     int64_t* rcache;        // [m_pad] rc of every arc under the current potentials, engine order
     const int64_t* adj_off; // [n_nodes] CSR over real nodes: entries of node u are adj[adj_off[u] .. adj_off[u+1])
     const int64_t* adj;     // [2m] (other end point << 32) | (engine arc << 1) | (1 when u is the arc's tail)
+    // double-buffered copy of the node positions (same flip as order[]): while the apply pass rewrites
+    // positions, posbuf[cur] stays the OLD, stable view the reduced-cost update tests membership against
+    int32_t* posbuf[2];     // [n_nodes] each, or nullptr
 };
 
 MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc) {
@@ -456,14 +459,18 @@ MCF_HD void mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
     // forced into private memory
     const int32_t* src = c.cur ? v.order[1] : v.order[0];
     int32_t* dst = c.cur ? v.order[0] : v.order[1];
+    int32_t* pnext = c.cur ? v.posbuf[0] : v.posbuf[1];
     if (j >= c.lo && j < c.hi) {
         bool in_t2;
         const int32_t i = mcf_apply_source(c, v.seg, j, &in_t2);
         const int32_t nd = src[i];
         dst[j] = nd;
         v.node[nd].pos = j;
+        if (pnext) pnext[nd] = j;
         if (in_t2) v.pi[nd] += c.sigma;
     } else {
-        dst[j] = src[j];  // catch up on what the previous apply changed in the other copy
+        const int32_t nd = src[j];
+        dst[j] = nd;  // catch up on what the previous apply changed in the other copy
+        if (pnext) pnext[nd] = j;
     }
 }

@@ -263,36 +263,45 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
     if (threadIdx.x == 0) cand[blockIdx.x] = McfCand{key, arc};
 }
 
-// ------------------------------------------------------------------ k_rcupd: keep the resident reduced costs exact
-// Runs after k_apply.  The swap shifted the potentials of the re-hung subtree T2 -- now the
-// contiguous slice order[b .. b+S) -- by sigma, so an arc changes iff exactly one end point is in
-// T2: +sigma when its tail is inside, -sigma when its head is.  16 lanes per T2 node walk its
-// CSR adjacency; every such arc is visited exactly once (from its inside end), so no atomics.
+// ------------------------------------------------------------------ keeping the resident reduced costs exact
+// The swap shifted the potentials of the re-hung subtree T2 by sigma, so an arc changes iff exactly
+// one end point is in T2: +sigma when its tail is inside, -sigma when its head is.  16 lanes per T2
+// node walk its CSR adjacency; every such arc is visited exactly once (from its inside end), so no
+// atomics.  The pass lives in k_update below.
 constexpr int kRcupdThreads = 256;
 constexpr int kMaxRcupdBlocks = 1024;
 
-__global__ __launch_bounds__(kRcupdThreads) void k_rcupd(McfView v) {
-    const McfCtx* c = v.ctx;
-    if (!c->apply) return;
-    const int32_t b = c->t2_new, S = c->t2_size;
-    const int64_t sigma = c->sigma;
-    const int32_t* __restrict__ ord = c->cur ? v.order[0] : v.order[1];  // the copy k_apply just wrote
+// ------------------------------------------------------------------ k_update = tree/potential apply + reduced-cost update in ONE launch
+// Resident-rc engines only.  The two halves touch disjoint data once T2 membership is tested
+// against the OLD positions (posbuf[cur], which this launch never writes) and T2 is enumerated
+// through the OLD order (order[cur][a0 .. a0+S)): the apply half writes order[cur^1],
+// posbuf[cur^1], node.pos and pi; the update half writes rcache.  One launch boundary less per pivot.
+__global__ __launch_bounds__(kRcupdThreads) void k_update(McfView v) {
+    const McfCtx c = *v.ctx;  // uniform: scalar loads
+    if (!c.apply) return;
+    const int64_t stride = (int64_t)gridDim.x * kRcupdThreads;
+    const int64_t tid = (int64_t)blockIdx.x * kRcupdThreads + threadIdx.x;
+    for (int64_t j = c.lo + tid; j < c.hi; j += stride) mcf_apply_one(v, c, (int32_t)j);
+    for (int64_t j = c.prev_lo + tid; j < c.prev_hi; j += stride)
+        if (j < c.lo || j >= c.hi) mcf_apply_one(v, c, (int32_t)j);
+
+    const int32_t a0 = c.t2_old, S = c.t2_size;
+    const int64_t sigma = c.sigma;
+    const int32_t* __restrict__ ord = c.cur ? v.order[1] : v.order[0];     // old order
+    const int32_t* __restrict__ pold = c.cur ? v.posbuf[1] : v.posbuf[0];  // old positions
     const int64_t* __restrict__ adj_off = v.adj_off;
     const int64_t* __restrict__ adj = v.adj;
-    const McfNode* __restrict__ node = v.node;
     int64_t* __restrict__ rcache = v.rcache;
     const int32_t sub = threadIdx.x & 15;
     const int64_t ngroups = (int64_t)gridDim.x * (kRcupdThreads / 16);
     for (int64_t t = (int64_t)blockIdx.x * (kRcupdThreads / 16) + (threadIdx.x >> 4); t < S; t += ngroups) {
-        const int32_t u = ord[b + t];
+        const int32_t u = ord[a0 + t];
         const int64_t beg = adj_off[u], end = adj_off[u + 1];
         for (int64_t p = beg + sub; p < end; p += 16) {
             const int64_t ent = adj[p];
-            const int32_t w = (int32_t)(ent >> 32);
-            const int32_t pw = node[w].pos;
-            if (pw >= b && pw < b + S) continue;  // both ends inside T2: unchanged
-            const int32_t e = (int32_t)((uint32_t)ent >> 1);
-            rcache[e] += (ent & 1) ? sigma : -sigma;
+            const int32_t pw = pold[(int32_t)(ent >> 32)];
+            if (pw >= a0 && pw < a0 + S) continue;  // both ends inside T2: unchanged
+            rcache[(int32_t)((uint32_t)ent >> 1)] += (ent & 1) ? sigma : -sigma;
         }
     }
 }
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     v.rec2 = reinterpret_cast<McfNode*>(smem + L.rec2);
     v.seg = reinterpret_cast<McfSeg*>(smem + L.seg);
     v.ctx = reinterpret_cast<McfCtx*>(smem + L.ctx);
+    v.posbuf[0] = v.posbuf[1] = nullptr;
 
     copy_words(smem + L.tail, g.tail, m_pad4);
     copy_words(smem + L.head, g.head, m_pad4);
@@ -593,6 +603,7 @@ struct mcf_handle {
     int32_t *d_order0 = nullptr, *d_order1 = nullptr, *d_path1 = nullptr, *d_path2 = nullptr;
     McfNode *d_rec1 = nullptr, *d_rec2 = nullptr;
     int64_t *d_rcache = nullptr, *d_adj_off = nullptr, *d_adj = nullptr;
+    int32_t *d_pos0 = nullptr, *d_pos1 = nullptr;
     bool rcached = false;     // large instance: resident reduced costs + k_rcupd
     int rcupd_blocks = 1;
     McfSeg* d_seg = nullptr;
@@ -656,8 +667,14 @@ int upload_image(mcf_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->d_node, im.node.data(), im.node.size() * sizeof(McfNode), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_order0, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_order1, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
-    if (h->rcached)
+    std::vector<int32_t> pos0;
+    if (h->rcached) {
         HIP_TRY(h, hipMemcpyAsync(h->d_rcache, im.rcache.data(), im.m_pad * 8, hipMemcpyHostToDevice, h->stream));
+        pos0.resize(im.n_nodes);
+        for (int32_t v = 0; v < im.n_nodes; ++v) pos0[v] = im.node[v].pos;
+        HIP_TRY(h, hipMemcpyAsync(h->d_pos0, pos0.data(), pos0.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_pos1, pos0.data(), pos0.size() * 4, hipMemcpyHostToDevice, h->stream));
+    }
     McfCtx c;
     std::memset(&c, 0, sizeof c);
     c.unbounded_arc = -1;
@@ -708,8 +725,12 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
 }
 
 void launch_apply(mcf_handle* h, hipStream_t s) {
-    hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
-    if (h->rcached) hipLaunchKernelGGL(k_rcupd, dim3(h->rcupd_blocks), dim3(kRcupdThreads), 0, s, h->view);
+    if (h->rcached) {  // tree/potential update and reduced-cost update in one launch
+        const int grid = h->apply_blocks > h->rcupd_blocks ? h->apply_blocks : h->rcupd_blocks;
+        hipLaunchKernelGGL(k_update, dim3(grid), dim3(kRcupdThreads), 0, s, h->view);
+    } else {
+        hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
+    }
 }
 
 void launch_pivot_triplet(mcf_handle* h, hipStream_t s) {
@@ -917,11 +938,15 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         if ((e = hipMemcpy(h->d_adj_off, im.adj_off.data(), im.adj_off.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("copy adj_off", e);
         if ((e = hipMemcpy(h->d_adj, im.adj.data(), im.adj.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("copy adj", e);
         h->im.adj.clear(); h->im.adj.shrink_to_fit();  // the device copy is the only one needed from here on
+        if ((e = dalloc(&h->d_pos0, N)) != hipSuccess) return fail("hipMalloc pos", e);
+        if ((e = dalloc(&h->d_pos1, N)) != hipSuccess) return fail("hipMalloc pos", e);
         v.rcache = h->d_rcache; v.adj_off = h->d_adj_off; v.adj = h->d_adj;
+        v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
         const int64_t rb = ((int64_t)im.n_nodes + 15) / 16;  // one 16-lane group per node of the largest possible T2
         h->rcupd_blocks = (int)(rb < kMaxRcupdBlocks ? (rb > 0 ? rb : 1) : kMaxRcupdBlocks);
     } else {
         v.rcache = nullptr; v.adj_off = nullptr; v.adj = nullptr;
+        v.posbuf[0] = v.posbuf[1] = nullptr;
     }
     const int rc = upload_image(h);
     if (rc != MCF_OK) { g_create_error = h->err; free_all(h); delete h; return rc; }

@@ -64,6 +64,7 @@ void bind(Emul& e) {
     v.rcache = nullptr;  // the emulation always prices by gathering potentials: an independent
     v.adj_off = nullptr; // check of the engine's resident reduced costs
     v.adj = nullptr;
+    v.posbuf[0] = v.posbuf[1] = nullptr;
 }
 
 // scalar stand-in for the pricing kernel: shard r of G, Devex block = ctx.block_index of
