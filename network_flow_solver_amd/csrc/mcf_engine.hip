@@ -320,8 +320,10 @@ __global__ __launch_bounds__(kPivotThreads) void k_reduce(const McfCand* __restr
 
 // ------------------------------------------------------------------ k_pivot
 __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView v, const McfCand* __restrict__ cand, int ncand,
-                                                          int32_t rule) {
-    if (v.ctx->status != MCF_RUNNING) {
+                                                          int32_t rule, int have_sweep) {
+    // candidate-list rule: slots without a pricing launch in front (have_sweep == 0) can only run
+    // minor iterations; once the list is exhausted they idle until the next slot that sweeps
+    if (v.ctx->status != MCF_RUNNING || (!have_sweep && v.ctx->minor_left <= 0)) {
         if (threadIdx.x == 0) v.ctx->apply = 0;
         return;
     }
@@ -733,10 +735,15 @@ void launch_apply(mcf_handle* h, hipStream_t s) {
     }
 }
 
-void launch_pivot_triplet(mcf_handle* h, hipStream_t s) {
+// One pivot slot.  Candidate-list rule: only every (minor_cap + 1)-th slot carries a pricing launch;
+// the slots in between go straight to k_pivot, which re-prices the list (a pricing launch there
+// would be a no-op anyway -- this just saves its launch boundary).
+void launch_pivot_triplet(mcf_handle* h, hipStream_t s, int slot = 0) {
     const int32_t rule = h->opt.rule;
-    launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG);
-    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, h->d_cand, h->price_blocks, rule);
+    int have_sweep = 1;
+    if (rule == MCF_RULE_CANDIDATE_LIST) have_sweep = slot % (mcf_minor_cap(h->price_blocks) + 1) == 0;
+    if (have_sweep) launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG);
+    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, h->d_cand, h->price_blocks, rule, have_sweep);
     launch_apply(h, s);
 }
 
@@ -745,7 +752,7 @@ int build_graph(mcf_handle* h, int batch) {
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
     HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream);
+    for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream, i);
     HIP_TRY(h, hipStreamEndCapture(h->stream, &h->graph));
     HIP_TRY(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
     h->graph_batch = batch;
@@ -766,7 +773,7 @@ int run_batch_profiled(mcf_handle* h, int batch) {
         HIP_TRY(h, hipEventRecord(ev[0], h->stream));
         launch_price(h, h->stream, h->view, rule, rule != MCF_RULE_DANTZIG);
         HIP_TRY(h, hipEventRecord(ev[1], h->stream));
-        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, h->stream, h->view, h->d_cand, h->price_blocks, rule);
+        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, h->stream, h->view, h->d_cand, h->price_blocks, rule, 1);
         HIP_TRY(h, hipEventRecord(ev[2], h->stream));
         launch_apply(h, h->stream);
         HIP_TRY(h, hipEventRecord(ev[3], h->stream));
@@ -1002,7 +1009,7 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
                                    h->small_layout, h->opt.rule, h->d_cand);
             else if (h->opt.profile) { rc = run_batch_profiled(h, batch); if (rc) return rc; }
             else if (graph) HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
-            else for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream);
+            else for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream, i);
             HIP_TRY(h, hipGetLastError());
             rc = read_ctx(h, h->stream);
             if (rc) return rc;
@@ -1154,7 +1161,7 @@ int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int
     if (!h || !cands_dev || ncand < 1) return MCF_E_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_pivot, dim3(1), dim3(kPivotThreads), 0, s, h->view, reinterpret_cast<const McfCand*>(cands_dev), ncand,
-                       h->opt.rule);
+                       h->opt.rule, 1);
     launch_apply(h, s);
     HIP_TRY(h, hipGetLastError());
     return MCF_OK;
