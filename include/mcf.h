@@ -163,9 +163,10 @@ int mcf_time_pricing(mcf_handle* h, int32_t rule, int32_t reps, double* ms_per_l
 int mcf_time_copy(int32_t device, int64_t bytes, int32_t reps, double* ms_per_copy);
 
 /* ---- introspection for the parity tests: raw tree state, host copies.
- * parent[n+1], pred_arc[n+1] (-1 for the root), size[n+1], pos[n+1], order[n+1], state[m]. */
+ * parent[n+1], pred_arc[n+1] (-1 for the root), size[n+1], pos[n+1], order[n+1], state[m],
+ * potential_with_root[n+1], depth[n+1].  Any pointer may be NULL. */
 int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
-                 int32_t* order, int8_t* state, int64_t* potential_with_root);
+                 int32_t* order, int8_t* state, int64_t* potential_with_root, int32_t* depth);
 
 /* Reduced cost of every arc (caller's order) as the pricing kernel sees it: the resident copy
  * when the handle keeps one (*resident = 1), else cost + pi[tail] - pi[head] computed on the host.

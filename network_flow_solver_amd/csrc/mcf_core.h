@@ -58,8 +58,11 @@ struct alignas(16) McfNode {
     int32_t parent;  // parent node (root: -1)
     int32_t pred;    // (tree arc to parent << 1) | up, up = 1 when tail[arc] == this node
     int32_t size;    // nodes in the subtree rooted here (>= 1)
-    int32_t pos;     // index of this node in the preorder array
+    int32_t depth;   // arcs between this node and the root
 };
+// Preorder positions are NOT part of the record: the apply pass rewrites ~0.4 n of them per pivot,
+// and keeping them out means the records the cycle walk chases are only written along the cycle
+// and inside the re-hung subtree.  They live in McfView::posbuf (double buffered like order[]).
 
 // Walk-side arc data, 16 bytes: residuals of a cycle arc come from one load.
 struct alignas(16) McfArcW {
@@ -82,6 +85,7 @@ struct alignas(16) McfCand {
 // new positions [dst, dst+len) take old positions [src, src+len).
 struct McfSeg {
     int32_t dst, src, len;
+    int32_t ddepth;  // what the depth of every node of the segment changes by
 };
 
 // Per-solve control block in device memory; the host only reads it between batches.
@@ -125,6 +129,7 @@ struct McfCtx {
     int32_t pv_vin, pv_leave;  // new parent of the re-hung subtree, leaving arc
     int32_t pv_leave_state;    // state the leaving arc takes (+1 ends at 0 flow, -1 at capacity)
     int32_t pv_tail_in_t2;
+    int32_t pv_vin_depth;      // depth of the new parent v_in
     int64_t pv_delta;
 };
 
@@ -154,9 +159,10 @@ struct McfView {
     int64_t* rcache;        // [m_pad] rc of every arc under the current potentials, engine order
     const int64_t* adj_off; // [n_nodes] CSR over real nodes: entries of node u are adj[adj_off[u] .. adj_off[u+1])
     const int64_t* adj;     // [2m] (other end point << 32) | (engine arc << 1) | (1 when u is the arc's tail)
-    // double-buffered copy of the node positions (same flip as order[]): while the apply pass rewrites
-    // positions, posbuf[cur] stays the OLD, stable view the reduced-cost update tests membership against
-    int32_t* posbuf[2];     // [n_nodes] each, or nullptr
+    // preorder position of every node, double buffered with the same flip as order[]: while the apply
+    // pass writes posbuf[cur ^ 1], posbuf[cur] stays the OLD, stable view (the walk's descriptor and the
+    // reduced-cost update's membership test read it)
+    int32_t* posbuf[2];     // [n_nodes] each
 };
 
 MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc) {
@@ -266,34 +272,40 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     // Tie rule for a strongly feasible tree: of all blocking arcs take the LAST one
     // met on that route starting from the join, i.e. first-side arcs lose ties to
     // the entering arc, which loses ties to second-side arcs.
+    // Depth-balanced climb: per round trip every side that is at least as deep as the other moves
+    // up one arc (both when they are level), so the walk costs max(d1, d2) dependent loads instead of
+    // d1 + d2; both parents' records and both arcs are requested before anything is looked at.
     int32_t u = first, w = second;
     McfNode ru = v.node[u], rw = v.node[w];
     int64_t d1 = MCF_INF, d2 = MCF_INF;
     int32_t k1 = -1, k2 = -1, n1 = 0, n2 = 0, ls1 = 1, ls2 = 1;
+    int32_t guard = 0;
     while (u != w) {
-        if (ru.size < rw.size) {
-            // the parent's record is the dependent chain: issue its load before the arc's
-            const McfNode nxt = v.node[ru.parent];
-            const McfArcW a = v.arcw[ru.pred >> 1];
+        const bool step_u = ru.depth >= rw.depth, step_w = rw.depth >= ru.depth;
+        McfNode nu = ru, nw = rw;
+        McfArcW au = McfArcW{0, 0}, aw = McfArcW{0, 0};
+        if (step_u) { nu = v.node[ru.parent]; au = v.arcw[ru.pred >> 1]; }
+        if (step_w) { nw = v.node[rw.parent]; aw = v.arcw[rw.pred >> 1]; }
+        if (step_u) {
             // first side is walked against the flow: an up arc loses flow, a down arc gains
-            const int64_t r = (ru.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
+            const int64_t r = (ru.pred & 1) ? au.flow : (au.cap >= MCF_INF ? MCF_INF : au.cap - au.flow);
             if (r < d1) { d1 = r; k1 = n1; ls1 = (ru.pred & 1) ? 1 : -1; }
             v.path1[n1] = u;
             v.rec1[n1] = ru;
             ++n1;
             u = ru.parent;
-            ru = nxt;
-        } else {
-            const McfNode nxt = v.node[rw.parent];
-            const McfArcW a = v.arcw[rw.pred >> 1];
-            const int64_t r = (rw.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
+            ru = nu;
+        }
+        if (step_w) {
+            const int64_t r = (rw.pred & 1) ? (aw.cap >= MCF_INF ? MCF_INF : aw.cap - aw.flow) : aw.flow;
             if (r <= d2) { d2 = r; k2 = n2; ls2 = (rw.pred & 1) ? -1 : 1; }
             v.path2[n2] = w;
             v.rec2[n2] = rw;
             ++n2;
             w = rw.parent;
-            rw = nxt;
+            rw = nw;
         }
+        if (++guard > v.n_nodes) { c->status = MCF_INTERNAL_ERROR; return; }  // depths out of sync: never spin
     }
     const int64_t de = v.arcw[e].cap;  // residual of the entering arc in its push direction
     int32_t result;
@@ -335,13 +347,17 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     c->pv_tail_in_t2 = tail_in_t2 ? 1 : 0;
     c->sigma = tail_in_t2 ? -rc : rc;  // potential shift that zeroes the entering arc's reduced cost
 
-    const int32_t S = rq.size, a0 = rq.pos;
+    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
+    const int32_t q = (result == 1 ? v.path1 : v.path2)[k];
+    const int32_t S = rq.size, a0 = pcur[q];
     // v_in's record: the first element of the other side, or the join itself when that side is empty
     const int32_t nother = result == 1 ? n2 : n1;
     const McfNode rvin = nother > 0 ? (result == 1 ? v.rec2[0] : v.rec1[0]) : ru;  // ru == rw == join record
+    const int32_t pvin = pcur[v_in];
+    c->pv_vin_depth = rvin.depth;
     // insertion point in OLD coordinates: directly behind v_in, or at the end of
     // v_in's block -- whichever moves fewer array elements
-    const int32_t tA = rvin.pos + 1, tB = rvin.pos + rvin.size;
+    const int32_t tA = pvin + 1, tB = pvin + rvin.size;
     const int32_t costA = tA <= a0 ? a0 - tA : tA - (a0 + S);
     const int32_t costB = tB <= a0 ? a0 - tB : tB - (a0 + S);
     const int32_t t = costA <= costB ? tA : tB;
@@ -403,25 +419,30 @@ MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
     // Old layout: block(s_i) = [p_i, p_i + z_i), nested, s_k = q.  New layout: block(s_0), then
     // for i = 1..k: s_i + what precedes block(s_{i-1}) inside block(s_i), then what follows it;
     // piece i starts at b + z_{i-1} because pieces 0..i-1 are exactly old block(s_{i-1}).
+    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
+    const int32_t base_depth = c->pv_vin_depth + 1;
     for (int32_t i = lane; i <= k; i += nlanes) {
         const McfNode r = srec[i];
+        const int32_t p = pcur[stem[i]];
+        const int32_t dd = base_depth + i - r.depth;  // piece i moves from depth(s_i) to depth(v_in) + 1 + i
         McfNode nr;
-        nr.pos = r.pos;  // rewritten by the apply pass
+        nr.depth = r.depth;  // the apply pass adds dd to every node of the piece, s_i included
         if (i == 0) {
             nr.parent = v_in;
             nr.pred = (e << 1) | c->pv_tail_in_t2;
             nr.size = S;
-            v.seg[0] = McfSeg{b, r.pos, r.size};
+            v.seg[0] = McfSeg{b, p, r.size, dd};
         } else {
             const McfNode rp = srec[i - 1];
+            const int32_t pp = pcur[stem[i - 1]];
             nr.parent = stem[i - 1];
             nr.pred = rp.pred ^ 1;  // the arc s_{i-1} used to hang on now carries s_i: direction bit flips
             nr.size = S - rp.size;  // all of T2 except what stays below s_{i-1}
-            const int32_t left = rp.pos - r.pos;                            // s_i itself + blocks before block(s_{i-1})
-            const int32_t right = (r.pos + r.size) - (rp.pos + rp.size);   // blocks after it (may be empty)
+            const int32_t left = pp - p;                            // s_i itself + blocks before block(s_{i-1})
+            const int32_t right = (p + r.size) - (pp + rp.size);   // blocks after it (may be empty)
             const int32_t dst = b + rp.size;
-            v.seg[2 * i - 1] = McfSeg{dst, r.pos, left};
-            v.seg[2 * i] = McfSeg{dst + left, rp.pos + rp.size, right};
+            v.seg[2 * i - 1] = McfSeg{dst, p, left, dd};
+            v.seg[2 * i] = McfSeg{dst + left, pp + rp.size, right, dd};
         }
         v.node[stem[i]] = nr;
     }
@@ -437,7 +458,7 @@ MCF_HD void mcf_pivot_seq(const McfView& v, int64_t best_key, int64_t best_arc, 
 // Data-parallel apply pass: new preorder position j  ->  old position.
 // Valid for j in [ctx.lo, ctx.hi).
 // ---------------------------------------------------------------------------
-MCF_HD int32_t mcf_apply_source(const McfCtx& c, const McfSeg* seg, int32_t j, bool* in_t2) {
+MCF_HD int32_t mcf_apply_source(const McfCtx& c, const McfSeg* seg, int32_t j, bool* in_t2, int32_t* ddepth) {
     const int32_t b = c.t2_new, S = c.t2_size, a0 = c.t2_old;
     if (j >= b && j < b + S) {
         *in_t2 = true;
@@ -446,9 +467,11 @@ MCF_HD int32_t mcf_apply_source(const McfCtx& c, const McfSeg* seg, int32_t j, b
             const int32_t mid = (lo + hi + 1) >> 1;
             if (seg[mid].dst <= j) lo = mid; else hi = mid - 1;
         }
+        *ddepth = seg[lo].ddepth;
         return seg[lo].src + (j - seg[lo].dst);
     }
     *in_t2 = false;
+    *ddepth = 0;
     // untouched nodes slide over the gap T2 leaves behind
     return b <= a0 ? j - S : j + S;
 }
@@ -462,15 +485,18 @@ MCF_HD void mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
     int32_t* pnext = c.cur ? v.posbuf[0] : v.posbuf[1];
     if (j >= c.lo && j < c.hi) {
         bool in_t2;
-        const int32_t i = mcf_apply_source(c, v.seg, j, &in_t2);
+        int32_t dd;
+        const int32_t i = mcf_apply_source(c, v.seg, j, &in_t2, &dd);
         const int32_t nd = src[i];
         dst[j] = nd;
-        v.node[nd].pos = j;
-        if (pnext) pnext[nd] = j;
-        if (in_t2) v.pi[nd] += c.sigma;
+        pnext[nd] = j;
+        if (in_t2) {
+            v.pi[nd] += c.sigma;
+            if (dd) v.node[nd].depth += dd;
+        }
     } else {
         const int32_t nd = src[j];
         dst[j] = nd;  // catch up on what the previous apply changed in the other copy
-        if (pnext) pnext[nd] = j;
+        pnext[nd] = j;
     }
 }

@@ -275,7 +275,7 @@ constexpr int kMaxRcupdBlocks = 1024;
 // Resident-rc engines only.  The two halves touch disjoint data once T2 membership is tested
 // against the OLD positions (posbuf[cur], which this launch never writes) and T2 is enumerated
 // through the OLD order (order[cur][a0 .. a0+S)): the apply half writes order[cur^1],
-// posbuf[cur^1], node.pos and pi; the update half writes rcache.  One launch boundary less per pivot.
+// posbuf[cur^1], pi and the depths of T2; the update half writes rcache.  One launch boundary less per pivot.
 __global__ __launch_bounds__(kRcupdThreads) void k_update(McfView v) {
     const McfCtx c = *v.ctx;  // uniform: scalar loads
     if (!c.apply) return;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
 // mcf_apply_one) and copies the state back.  Same arc sets, same tie rule, same core functions
 // as the three-kernel path, so the pivot sequence is identical.
 struct SmallLayout {
-    uint32_t tail, head, cost, orig, state, weight, arcw, pi, node, order0, order1, path1, path2, rec1, rec2, seg, ctx, total;
+    uint32_t tail, head, cost, orig, state, weight, arcw, pi, node, order0, order1, pos0, pos1, path1, path2, rec1, rec2, seg, ctx, total;
 };
 
 constexpr int kSmallThreads = 1024;
@@ -433,7 +433,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     v.rec2 = reinterpret_cast<McfNode*>(smem + L.rec2);
     v.seg = reinterpret_cast<McfSeg*>(smem + L.seg);
     v.ctx = reinterpret_cast<McfCtx*>(smem + L.ctx);
-    v.posbuf[0] = v.posbuf[1] = nullptr;
+    v.posbuf[0] = reinterpret_cast<int32_t*>(smem + L.pos0);
+    v.posbuf[1] = reinterpret_cast<int32_t*>(smem + L.pos1);
 
     copy_words(smem + L.tail, g.tail, m_pad4);
     copy_words(smem + L.head, g.head, m_pad4);
@@ -446,6 +447,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     copy_words(smem + L.node, g.node, N * 16u);
     copy_words(smem + L.order0, g.order[0], N * 4u);
     copy_words(smem + L.order1, g.order[1], N * 4u);
+    copy_words(smem + L.pos0, g.posbuf[0], N * 4u);
+    copy_words(smem + L.pos1, g.posbuf[1], N * 4u);
     copy_words(smem + L.ctx, g.ctx, (uint32_t)sizeof(McfCtx));
     __syncthreads();
     STAMP(0);
@@ -565,6 +568,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     copy_words(g.node, smem + L.node, N * 16u);
     copy_words(g.order[0], smem + L.order0, N * 4u);
     copy_words(g.order[1], smem + L.order1, N * 4u);
+    copy_words(g.posbuf[0], smem + L.pos0, N * 4u);
+    copy_words(g.posbuf[1], smem + L.pos1, N * 4u);
     copy_words(g.ctx, smem + L.ctx, (uint32_t)sizeof(McfCtx));
     if (listing && threadIdx.x < MCF_NUM_BUCKETS) list[threadIdx.x] = McfCand{s_lk[threadIdx.x], s_la[threadIdx.x]};
 #ifdef MCF_STAMPS
@@ -669,14 +674,10 @@ int upload_image(mcf_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->d_node, im.node.data(), im.node.size() * sizeof(McfNode), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_order0, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_order1, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
-    std::vector<int32_t> pos0;
-    if (h->rcached) {
+    HIP_TRY(h, hipMemcpyAsync(h->d_pos0, im.pos.data(), im.pos.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_pos1, im.pos.data(), im.pos.size() * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->rcached)
         HIP_TRY(h, hipMemcpyAsync(h->d_rcache, im.rcache.data(), im.m_pad * 8, hipMemcpyHostToDevice, h->stream));
-        pos0.resize(im.n_nodes);
-        for (int32_t v = 0; v < im.n_nodes; ++v) pos0[v] = im.node[v].pos;
-        HIP_TRY(h, hipMemcpyAsync(h->d_pos0, pos0.data(), pos0.size() * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_pos1, pos0.data(), pos0.size() * 4, hipMemcpyHostToDevice, h->stream));
-    }
     McfCtx c;
     std::memset(&c, 0, sizeof c);
     c.unbounded_arc = -1;
@@ -891,6 +892,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     if ((e = dalloc(&h->d_node, N)) != hipSuccess) return fail("hipMalloc node", e);
     if ((e = dalloc(&h->d_order0, N)) != hipSuccess) return fail("hipMalloc order", e);
     if ((e = dalloc(&h->d_order1, N)) != hipSuccess) return fail("hipMalloc order", e);
+    if ((e = dalloc(&h->d_pos0, N)) != hipSuccess) return fail("hipMalloc pos", e);
+    if ((e = dalloc(&h->d_pos1, N)) != hipSuccess) return fail("hipMalloc pos", e);
     if ((e = dalloc(&h->d_path1, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_path2, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_rec1, N)) != hipSuccess) return fail("hipMalloc rec", e);
@@ -912,6 +915,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     v.weight = opt.rule == MCF_RULE_DEVEX_BLOCK ? h->d_weight : nullptr;
     v.arcw = h->d_arcw; v.pi = h->d_pi; v.node = h->d_node;
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
+    v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
     v.path1 = h->d_path1; v.path2 = h->d_path2; v.rec1 = h->d_rec1; v.rec2 = h->d_rec2; v.seg = h->d_seg; v.ctx = h->d_ctx;
 
     {
@@ -923,11 +927,12 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         L.tail = take(mp * 4); L.head = take(mp * 4); L.cost = take(mp * 4); L.orig = take(mp * 4);
         L.state = take(mp); L.weight = take(opt.rule == MCF_RULE_DEVEX_BLOCK ? mp * 4 : 0);
         L.arcw = take((uint64_t)im.arcw.size() * 16); L.pi = take(Nn * 8); L.node = take(Nn * 16);
-        L.order0 = take(Nn * 4); L.order1 = take(Nn * 4); L.path1 = take(Nn * 4); L.path2 = take(Nn * 4);
+        L.order0 = take(Nn * 4); L.order1 = take(Nn * 4); L.pos0 = take(Nn * 4); L.pos1 = take(Nn * 4);
+        L.path1 = take(Nn * 4); L.path2 = take(Nn * 4);
         L.rec1 = take(Nn * 16); L.rec2 = take(Nn * 16);
         L.seg = take((2 * Nn + 2) * sizeof(McfSeg)); L.ctx = take(sizeof(McfCtx));
         L.total = off;
-        const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 92 + 4096;
+        const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 104 + 4096;
         h->small = !opt.no_fused && !opt.profile && h->shards == 1 && need < 150 * 1024 && L.total <= 158 * 1024;
         if (h->small) {
             hipError_t fe = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small),
@@ -945,15 +950,11 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         if ((e = hipMemcpy(h->d_adj_off, im.adj_off.data(), im.adj_off.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("copy adj_off", e);
         if ((e = hipMemcpy(h->d_adj, im.adj.data(), im.adj.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("copy adj", e);
         h->im.adj.clear(); h->im.adj.shrink_to_fit();  // the device copy is the only one needed from here on
-        if ((e = dalloc(&h->d_pos0, N)) != hipSuccess) return fail("hipMalloc pos", e);
-        if ((e = dalloc(&h->d_pos1, N)) != hipSuccess) return fail("hipMalloc pos", e);
         v.rcache = h->d_rcache; v.adj_off = h->d_adj_off; v.adj = h->d_adj;
-        v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
         const int64_t rb = ((int64_t)im.n_nodes + 15) / 16;  // one 16-lane group per node of the largest possible T2
         h->rcupd_blocks = (int)(rb < kMaxRcupdBlocks ? (rb > 0 ? rb : 1) : kMaxRcupdBlocks);
     } else {
         v.rcache = nullptr; v.adj_off = nullptr; v.adj = nullptr;
-        v.posbuf[0] = v.posbuf[1] = nullptr;
     }
     const int rc = upload_image(h);
     if (rc != MCF_OK) { g_create_error = h->err; free_all(h); delete h; return rc; }
@@ -1238,7 +1239,7 @@ int mcf_time_copy(int32_t device, int64_t bytes, int32_t reps, double* ms_per_co
 }
 
 int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos, int32_t* order,
-                 int8_t* state, int64_t* potential_with_root) {
+                 int8_t* state, int64_t* potential_with_root, int32_t* depth) {
     if (!h) return MCF_E_BAD_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = read_ctx(h, h->stream);
@@ -1253,12 +1254,11 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
             pred_arc[v] = a < 0 ? -1 : (a < im.m ? im.orig[a] : (int32_t)a);  // artificial arcs keep m + node
         }
         if (size) size[v] = nodes[v].size;
-        if (pos) pos[v] = nodes[v].pos;
+        if (depth) depth[v] = nodes[v].depth;
     }
-    if (order) {
-        const int cur = h->h_ctx->cur ^ (h->h_ctx->pending_flip ? 1 : 0);
-        HIP_TRY(h, hipMemcpy(order, cur ? h->d_order1 : h->d_order0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
-    }
+    const int cur = h->h_ctx->cur ^ (h->h_ctx->pending_flip ? 1 : 0);
+    if (order) HIP_TRY(h, hipMemcpy(order, cur ? h->d_order1 : h->d_order0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
+    if (pos) HIP_TRY(h, hipMemcpy(pos, cur ? h->d_pos1 : h->d_pos0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
     if (state) {
         std::vector<int8_t> st(im.m_pad);
         HIP_TRY(h, hipMemcpy(st.data(), h->d_state, st.size(), hipMemcpyDeviceToHost));

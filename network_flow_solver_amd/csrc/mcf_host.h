@@ -31,6 +31,7 @@ struct McfHostImage {
     std::vector<int64_t> pi;                // [n_nodes]
     std::vector<McfNode> node;              // [n_nodes]
     std::vector<int32_t> order;             // [n_nodes]
+    std::vector<int32_t> pos;               // [n_nodes] preorder position of every node (inverse of order)
     std::vector<int64_t> supply;            // [n]
     // resident reduced costs + node->arc adjacency (mcf_build_rcache)
     std::vector<int64_t> rcache;            // [m_pad]
@@ -127,8 +128,10 @@ inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, co
     im.pi.assign(im.n_nodes, 0);
     im.node.assign(im.n_nodes, McfNode{-1, -1, 1, 0});
     im.order.assign(im.n_nodes, 0);
+    im.pos.assign(im.n_nodes, 0);
     im.node[root] = McfNode{-1, -1, im.n_nodes, 0};
     im.order[0] = root;
+    im.pos[root] = 0;
     for (int32_t v = 0; v < n; ++v) {
         const int64_t a = m + v;
         const int64_t s = supply[v];
@@ -137,8 +140,9 @@ inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, co
         const int32_t up = s >= 0 ? 1 : 0;
         im.arcw[a] = McfArcW{MCF_INF, s >= 0 ? s : -s};
         im.pi[v] = up ? -im.big_m : im.big_m;
-        im.node[v] = McfNode{root, (int32_t)((a << 1) | up), 1, v + 1};
+        im.node[v] = McfNode{root, (int32_t)((a << 1) | up), 1, 1};  // depth 1: hangs off the root
         im.order[v + 1] = v;
+        im.pos[v] = v + 1;
     }
     *err_code = 0;
     return "";

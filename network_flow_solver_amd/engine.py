@@ -103,7 +103,7 @@ def load_library():
     lib.mcf_set_max_pivots.argtypes = [vp, ctypes.c_int64]
     lib.mcf_time_pricing.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     lib.mcf_time_copy.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
-    lib.mcf_get_tree.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i8p, i64p]
+    lib.mcf_get_tree.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i8p, i64p, i32p]
     lib.mcf_get_reduced_costs.argtypes = [vp, i64p, i32p]
     lib.mcf_dimacs_scan.argtypes = [ctypes.c_char_p, i64p, i64p, ctypes.c_char_p, ctypes.c_int32]
     lib.mcf_dimacs_load.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, i64p,
@@ -262,13 +262,13 @@ class McfEngine:
 
     def tree(self) -> dict:
         N = self.n + 1
-        parent, pred, size, pos, order = (np.zeros(N, dtype=np.int32) for _ in range(5))
+        parent, pred, size, pos, order, depth = (np.zeros(N, dtype=np.int32) for _ in range(6))
         state = np.zeros(max(self.m, 1), dtype=np.int8)
         pi = np.zeros(N, dtype=np.int64)
         i32 = ctypes.c_int32
         self._check(self._lib.mcf_get_tree(self._h, _p(parent, i32), _p(pred, i32), _p(size, i32), _p(pos, i32),
-                                           _p(order, i32), _p(state, ctypes.c_int8), _p(pi, ctypes.c_int64)))
-        return {"parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order,
+                                           _p(order, i32), _p(state, ctypes.c_int8), _p(pi, ctypes.c_int64), _p(depth, i32)))
+        return {"parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order, "depth": depth,
                 "state": state[: self.m], "pi": pi}
 
     def reduced_costs(self):

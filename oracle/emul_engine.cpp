@@ -20,7 +20,7 @@ namespace {
 
 struct Emul {
     McfHostImage im;
-    std::vector<int32_t> order1, path1, path2;
+    std::vector<int32_t> order1, path1, path2, pos1;
     std::vector<McfNode> rec1, rec2;
     std::vector<McfSeg> seg;
     McfCtx ctx;
@@ -33,11 +33,12 @@ struct Emul {
 void bind(Emul& e) {
     McfHostImage& im = e.im;
     e.order1 = im.order;
+    e.pos1 = im.pos;
     e.path1.assign(im.n_nodes, 0);
     e.path2.assign(im.n_nodes, 0);
     e.rec1.assign(im.n_nodes, McfNode{0, 0, 0, 0});
     e.rec2.assign(im.n_nodes, McfNode{0, 0, 0, 0});
-    e.seg.assign(2 * (size_t)im.n_nodes + 2, McfSeg{0, 0, 0});
+    e.seg.assign(2 * (size_t)im.n_nodes + 2, McfSeg{0, 0, 0, 0});
     std::memset(&e.ctx, 0, sizeof e.ctx);
     e.ctx.unbounded_arc = -1;
     McfView& v = e.view;
@@ -64,7 +65,8 @@ void bind(Emul& e) {
     v.rcache = nullptr;  // the emulation always prices by gathering potentials: an independent
     v.adj_off = nullptr; // check of the engine's resident reduced costs
     v.adj = nullptr;
-    v.posbuf[0] = v.posbuf[1] = nullptr;
+    v.posbuf[0] = im.pos.data();
+    v.posbuf[1] = e.pos1.data();
 }
 
 // scalar stand-in for the pricing kernel: shard r of G, Devex block = ctx.block_index of
@@ -139,7 +141,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
                const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int64_t max_pivots,
                int32_t* status, int64_t* objective_hi_lo, int64_t* flow, int64_t* potential, int8_t* in_tree,
                int64_t* stats /*[12]*/, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
-               int32_t* order, int64_t* trace_arcs, int64_t trace_cap, int32_t bucketed) {
+               int32_t* order, int64_t* trace_arcs, int64_t trace_cap, int32_t bucketed, int32_t* depth) {
     Emul e;
     e.rule = rule;
     int err = 0;
@@ -186,6 +188,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     stats[8] = r.artificial_flow; stats[9] = (int64_t)(secs * 1e9);
     stats[10] = c.minor_pivots; stats[11] = c.major_sweeps;
     const int32_t* ord = e.view.order[c.cur];
+    const int32_t* pcur = e.view.posbuf[c.cur];
     for (int32_t v = 0; v <= n; ++v) {
         if (parent) parent[v] = e.im.node[v].parent;
         if (pred_arc) {
@@ -193,7 +196,8 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
             pred_arc[v] = a < 0 ? -1 : (a < m ? e.im.orig[a] : (int32_t)a);  // artificial arcs keep m + node
         }
         if (size) size[v] = e.im.node[v].size;
-        if (pos) pos[v] = e.im.node[v].pos;
+        if (pos) pos[v] = pcur[v];
+        if (depth) depth[v] = e.im.node[v].depth;
         if (order) order[v] = ord[v];
     }
     return 0;

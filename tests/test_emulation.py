@@ -16,7 +16,7 @@ def test_integer_engine_reaches_reference_optimum(entry, inst, rule):
     res = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
     assert res["status"] == "optimal"
     assert res["objective"] == int(round(exp["objective"]))          # bit-exact integer objective
-    check_tree_invariants(inst.n, res["parent"], res["size"], res["pos"], res["order"])
+    check_tree_invariants(inst.n, res["parent"], res["size"], res["pos"], res["order"], res["depth"])
     rc = check_optimality(inst, res["flow"], res["potential"])
     if optimum_is_unique(inst, res["flow"], res["in_tree"], rc):
         got = {(int(inst.tail[i]), int(inst.head[i])): float(res["flow"][i]) for i in range(inst.m) if res["flow"][i]}
@@ -27,7 +27,7 @@ def test_tree_invariants_hold_after_every_pivot():
     _, inst = load_synthetic()[0]
     for cap in range(1, 140):
         res = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0, max_pivots=cap)
-        check_tree_invariants(inst.n, res["parent"], res["size"], res["pos"], res["order"])
+        check_tree_invariants(inst.n, res["parent"], res["size"], res["pos"], res["order"], res["depth"])
         if res["status"] == "optimal":
             break
     assert res["status"] == "optimal"

@@ -38,7 +38,7 @@ def test_synthetic_goldens_exact(gpu_engine_module, entry, inst, rule):
     res, tree = _solve(gpu_engine_module, inst, rule)
     assert res.status == "optimal"
     assert res.objective == int(round(exp["objective"]))
-    check_tree_invariants(inst.n, tree["parent"], tree["size"], tree["pos"], tree["order"])
+    check_tree_invariants(inst.n, tree["parent"], tree["size"], tree["pos"], tree["order"], tree["depth"])
     rc = check_optimality(inst, res.flow, res.potential)
     if optimum_is_unique(inst, res.flow, res.in_tree, rc):
         got = {(int(inst.tail[i]), int(inst.head[i])): float(res.flow[i]) for i in range(inst.m) if res.flow[i]}
