@@ -81,7 +81,8 @@ typedef struct mcf_options {
     int32_t price_blocks;    /* pricing grid size; 0 = auto */
     int32_t no_fused;        /* 1 = never use the fused LDS-resident kernel for small instances */
     int32_t no_rcache;       /* 1 = never keep reduced costs resident: always price by gathering potentials */
-    int32_t reserved;
+    int32_t cycle_scan;      /* cycle search: 0 = auto, -1 = always climb parent pointers, k >= 1 = climb k - 1 round
+                                trips, then finish by the position-space scan (1 = scan only) */
 } mcf_options;
 
 typedef struct mcf_stats {
@@ -107,6 +108,8 @@ typedef struct mcf_stats {
                                  -1 when mcf_get_result was asked for neither status, objective nor flow */
     int64_t pricing_mode;     /* 0 = gather sweep (k_price), 1 = resident reduced costs (k_price_rc + k_rcupd),
                                  2 = fused LDS-resident pivot loop (k_solve_small) */
+    int64_t cycle_scans;      /* pivots whose cycle was completed by the position-space scan */
+    int64_t scan_rounds;      /* chunk iterations of those scans */
 } mcf_stats;
 
 /* Called from mcf_solve every cb_interval pivots (simplex.py:1143-1154).
@@ -164,9 +167,10 @@ int mcf_time_copy(int32_t device, int64_t bytes, int32_t reps, double* ms_per_co
 
 /* ---- introspection for the parity tests: raw tree state, host copies.
  * parent[n+1], pred_arc[n+1] (-1 for the root), size[n+1], pos[n+1], order[n+1], state[m],
- * potential_with_root[n+1], depth[n+1].  Any pointer may be NULL. */
+ * potential_with_root[n+1], depth[n+1], psize[n+1] (subtree size of the node at each preorder
+ * position).  Any pointer may be NULL. */
 int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
-                 int32_t* order, int8_t* state, int64_t* potential_with_root, int32_t* depth);
+                 int32_t* order, int8_t* state, int64_t* potential_with_root, int32_t* depth, int32_t* psize);
 
 /* Reduced cost of every arc (caller's order) as the pricing kernel sees it: the resident copy
  * when the handle keeps one (*resident = 1), else cost + pi[tail] - pi[head] computed on the host.

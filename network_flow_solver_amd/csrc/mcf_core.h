@@ -32,6 +32,20 @@
 
 #define MCF_INF ((int64_t)1 << 60)  // "uncapacitated" sentinel; also ratio-test infinity
 
+// Team primitives of the cooperative passes (mcf_pivot_scan): a workgroup on the device, a single
+// "lane" in the host emulation build (where a barrier is nothing and an atomic is a plain update).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MCF_TEAM_BARRIER() __syncthreads()
+#define MCF_ATOMIC_MIN64(p, x) atomicMin(reinterpret_cast<long long*>(p), (long long)(x))
+#define MCF_ATOMIC_MIN32(p, x) atomicMin(reinterpret_cast<int*>(p), (int)(x))
+#define MCF_ATOMIC_MAX32(p, x) atomicMax(reinterpret_cast<int*>(p), (int)(x))
+#else
+#define MCF_TEAM_BARRIER() ((void)0)
+#define MCF_ATOMIC_MIN64(p, x) do { if ((int64_t)(x) < *(p)) *(p) = (int64_t)(x); } while (0)
+#define MCF_ATOMIC_MIN32(p, x) do { if ((int32_t)(x) < *(p)) *(p) = (int32_t)(x); } while (0)
+#define MCF_ATOMIC_MAX32(p, x) do { if ((int32_t)(x) > *(p)) *(p) = (int32_t)(x); } while (0)
+#endif
+
 enum McfStatus : int32_t {
     MCF_RUNNING = 0,
     MCF_OPTIMAL = 1,        // no eligible arc left
@@ -130,7 +144,15 @@ struct McfCtx {
     int32_t pv_leave_state;    // state the leaving arc takes (+1 ends at 0 flow, -1 at capacity)
     int32_t pv_tail_in_t2;
     int32_t pv_vin_depth;      // depth of the new parent v_in
+    int32_t pv_first, pv_second;  // end points of the entering arc in push order
+    int64_t pv_rc;             // its exact reduced cost
     int64_t pv_delta;
+    // ---- cycle search: round trips the pointer-chasing climb may take before the position-space scan
+    // takes over (only when the view carries psz[]); diagnostics
+    int32_t climb_budget;
+    int32_t pad0;
+    int64_t scans;             // pivots whose cycle was completed by the scan
+    int64_t scan_rounds;       // chunk iterations of those scans
 };
 
 // Raw views the core functions operate on (device pointers in the kernels,
@@ -163,6 +185,11 @@ struct McfView {
     // pass writes posbuf[cur ^ 1], posbuf[cur] stays the OLD, stable view (the walk's descriptor and the
     // reduced-cost update's membership test read it)
     int32_t* posbuf[2];     // [n_nodes] each
+    // subtree sizes in POSITION space (psz[cur][pos[v]] == size[v]), double buffered like order[], or
+    // nullptr.  With it, "the node at position i is an ancestor of u" is i <= pos[u] < i + psz[i]: the
+    // cycle can be found by a coalesced team-wide scan over preorder positions instead of a pointer
+    // chase whose length is the tree depth (mcf_pivot_scan).
+    int32_t* psz[2];        // [n_nodes] each
 };
 
 MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc) {
@@ -217,7 +244,26 @@ MCF_HD int64_t mcf_minor_key(const McfView& v, int64_t packed_arc) {
 //         bookkeeping, stem re-parenting, the segments of the block permutation.  Each path
 //         element has a closed form from the recorded records, so lanes just stride over them.
 // ---------------------------------------------------------------------------
-MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
+// State of the cycle search, shared by the climb (one lane) and the scan (the whole team).
+struct McfCycle {
+    int64_t d1, d2;        // smallest residual so far on the first / second side (MCF_INF: none)
+    int32_t k1, k2;        // index of that blocking node in path1 / path2 (-1: none)
+    int32_t n1, n2;        // path elements recorded so far
+    int32_t u, w;          // where the two climbs stand; u == w: that node is the join
+    McfNode ru, rw;        // their records
+};
+
+// Accumulators of the team-wide scan (LDS on the device).
+struct McfScanAcc {
+    int64_t r1, r2;        // smallest residual met by the scan on either side
+    int32_t i1, i2;        // path index that goes with it (side 1: lowest, side 2: highest among ties)
+    int32_t jpos;          // preorder position of the deepest common ancestor met so far, -1: none yet
+    int32_t rounds;
+};
+
+// Step 1 (one lane): bookkeeping + the entering arc.  Returns false when there is nothing to pivot on
+// in this slot (limit reached, no candidate, ...); the control block then already says why.
+MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
     McfCtx* c = v.ctx;
     c->apply = 0;
     c->stage = 0;
@@ -227,7 +273,7 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
         c->prev_hi = c->hi;
         c->pending_flip = 0;
     }
-    if (c->pivots >= c->max_pivots) { c->status = MCF_PIVOT_LIMIT; return; }
+    if (c->pivots >= c->max_pivots) { c->status = MCF_PIVOT_LIMIT; return false; }
 
     const bool minor = rule == MCF_RULE_CANDIDATE_LIST && c->minor_left > 0;
     if (rule == MCF_RULE_CANDIDATE_LIST && !minor) c->major_sweeps += 1;
@@ -244,7 +290,7 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
         } else {
             c->status = MCF_OPTIMAL;
         }
-        return;
+        return false;
     }
     c->empty_blocks = 0;
     if (rule == MCF_RULE_CANDIDATE_LIST) {
@@ -267,20 +313,39 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     // exact reduced cost of the entering arc (the Devex key is a merit, not a violation)
     const int64_t rc = (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
 
-    // --- join search + ratio test (basis.py:207-241, simplex.py:1201-1229).
-    // Flow is pushed second -> join -> first -> (entering arc) -> second.
-    // Tie rule for a strongly feasible tree: of all blocking arcs take the LAST one
-    // met on that route starting from the join, i.e. first-side arcs lose ties to
-    // the entering arc, which loses ties to second-side arcs.
+    c->pv_e = e; c->pv_s = s; c->pv_first = first; c->pv_second = second; c->pv_rc = rc;
+    return true;
+}
+
+// Step 2a (one lane): the cycle by pointer chasing, at most `budget` round trips.
+// --- join search + ratio test (basis.py:207-241, simplex.py:1201-1229).
+// Flow is pushed second -> join -> first -> (entering arc) -> second.
+// Tie rule for a strongly feasible tree: of all blocking arcs take the LAST one
+// met on that route starting from the join, i.e. first-side arcs lose ties to
+// the entering arc, which loses ties to second-side arcs.
+MCF_HD void mcf_cycle_init(const McfView& v, McfCycle* cy) {
+    const McfCtx* c = v.ctx;
+    cy->u = c->pv_first;
+    cy->w = c->pv_second;
+    cy->ru = v.node[cy->u];
+    cy->rw = v.node[cy->w];
+    cy->d1 = MCF_INF; cy->d2 = MCF_INF;
+    cy->k1 = -1; cy->k2 = -1;
+    cy->n1 = 0; cy->n2 = 0;
+}
+
+// Returns false on an internal error (depths out of sync).  On return cy->u == cy->w means joined.
+MCF_HD bool mcf_pivot_climb(const McfView& v, McfCycle* cy, int32_t budget) {
+    McfCtx* c = v.ctx;
     // Depth-balanced climb: per round trip every side that is at least as deep as the other moves
     // up one arc (both when they are level), so the walk costs max(d1, d2) dependent loads instead of
     // d1 + d2; both parents' records and both arcs are requested before anything is looked at.
-    int32_t u = first, w = second;
-    McfNode ru = v.node[u], rw = v.node[w];
-    int64_t d1 = MCF_INF, d2 = MCF_INF;
-    int32_t k1 = -1, k2 = -1, n1 = 0, n2 = 0, ls1 = 1, ls2 = 1;
-    int32_t guard = 0;
-    while (u != w) {
+    int32_t u = cy->u, w = cy->w;
+    McfNode ru = cy->ru, rw = cy->rw;
+    int64_t d1 = cy->d1, d2 = cy->d2;
+    int32_t k1 = cy->k1, k2 = cy->k2, n1 = cy->n1, n2 = cy->n2;
+    int32_t trips = 0;
+    while (u != w && trips < budget) {
         const bool step_u = ru.depth >= rw.depth, step_w = rw.depth >= ru.depth;
         McfNode nu = ru, nw = rw;
         McfArcW au = McfArcW{0, 0}, aw = McfArcW{0, 0};
@@ -289,7 +354,7 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
         if (step_u) {
             // first side is walked against the flow: an up arc loses flow, a down arc gains
             const int64_t r = (ru.pred & 1) ? au.flow : (au.cap >= MCF_INF ? MCF_INF : au.cap - au.flow);
-            if (r < d1) { d1 = r; k1 = n1; ls1 = (ru.pred & 1) ? 1 : -1; }
+            if (r < d1) { d1 = r; k1 = n1; }
             v.path1[n1] = u;
             v.rec1[n1] = ru;
             ++n1;
@@ -298,15 +363,130 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
         }
         if (step_w) {
             const int64_t r = (rw.pred & 1) ? (aw.cap >= MCF_INF ? MCF_INF : aw.cap - aw.flow) : aw.flow;
-            if (r <= d2) { d2 = r; k2 = n2; ls2 = (rw.pred & 1) ? -1 : 1; }
+            if (r <= d2) { d2 = r; k2 = n2; }
             v.path2[n2] = w;
             v.rec2[n2] = rw;
             ++n2;
             w = rw.parent;
             rw = nw;
         }
-        if (++guard > v.n_nodes) { c->status = MCF_INTERNAL_ERROR; return; }  // depths out of sync: never spin
+        if (++trips > v.n_nodes) { c->status = MCF_INTERNAL_ERROR; return false; }  // depths out of sync: never spin
     }
+    cy->u = u; cy->w = w; cy->ru = ru; cy->rw = rw;
+    cy->d1 = d1; cy->d2 = d2; cy->k1 = k1; cy->k2 = k2; cy->n1 = n1; cy->n2 = n2;
+    return true;
+}
+
+// Step 2b (the whole team): the rest of the cycle by a scan over preorder positions.
+//
+// The node at position i is an ancestor of x (x included) iff i <= pos[x] < i + psz[i].  The nodes
+// still missing from the two paths are exactly the ancestors of cy->u that are not ancestors of
+// cy->w (first side) and vice versa; common ancestors lie at lower positions than all of them and
+// the join is the common ancestor with the highest position.  So the team sweeps the positions
+// downwards from max(pos[u], pos[w]) in chunks of nlanes * kScanK coalesced loads and stops after the
+// first chunk that holds a common ancestor.  A found ancestor a of u goes to path index
+// n1 + depth[u] - depth[a] (the depth field makes a compaction unnecessary), its record next to it,
+// exactly what the climb would have recorded.  Ratio test: every lane keeps the best residual of
+// the elements it met (side 1: lowest index among ties, side 2: highest -- the climb's `<` / `<=`);
+// two team-wide atomic minima + one tie pass combine them.  The number of dependent memory round
+// trips is ~4 per chunk whatever the length of the cycle.
+#define MCF_SCAN_K 4
+MCF_HD void mcf_pivot_scan(const McfView& v, McfCycle* cy, McfScanAcc* acc, int32_t lane, int32_t nlanes) {
+    McfCtx* c = v.ctx;
+    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
+    const int32_t* ord = c->cur ? v.order[1] : v.order[0];
+    const int32_t* psz = c->cur ? v.psz[1] : v.psz[0];
+    if (lane == 0) {
+        acc->r1 = INT64_MAX; acc->r2 = INT64_MAX;
+        acc->i1 = INT32_MAX; acc->i2 = -1;
+        acc->jpos = -1; acc->rounds = 0;
+    }
+    const int32_t u = cy->u, w = cy->w;
+    const int32_t pu = pcur[u], pw = pcur[w], du = cy->ru.depth, dw = cy->rw.depth;
+    const int32_t base1 = cy->n1, base2 = cy->n2;
+    MCF_TEAM_BARRIER();
+    int64_t b1r = INT64_MAX, b2r = INT64_MAX;
+    int32_t b1i = -1, b2i = -1;
+    int32_t top = (pu > pw ? pu : pw) + 1;  // exclusive
+    bool failed = false;
+    for (;;) {
+        const int32_t lo = top - nlanes * MCF_SCAN_K;
+        int32_t sz[MCF_SCAN_K];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 0; k < MCF_SCAN_K; ++k) {
+            const int32_t i = lo + k * nlanes + lane;
+            sz[k] = i >= 0 ? psz[i] : 0;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 0; k < MCF_SCAN_K; ++k) {
+            const int32_t i = lo + k * nlanes + lane;
+            if (i < 0) continue;
+            const bool au = i <= pu && pu - i < sz[k];
+            const bool aw = i <= pw && pw - i < sz[k];
+            if (!au && !aw) continue;
+            if (au && aw) { MCF_ATOMIC_MAX32(&acc->jpos, i); continue; }
+            const int32_t nd = ord[i];
+            const McfNode rec = v.node[nd];
+            const McfArcW a = v.arcw[rec.pred >> 1];
+            if (au) {
+                const int32_t idx = base1 + du - rec.depth;
+                v.path1[idx] = nd;
+                v.rec1[idx] = rec;
+                const int64_t r = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
+                if (r < b1r || (r == b1r && idx < b1i)) { b1r = r; b1i = idx; }
+            } else {
+                const int32_t idx = base2 + dw - rec.depth;
+                v.path2[idx] = nd;
+                v.rec2[idx] = rec;
+                const int64_t r = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
+                if (r < b2r || (r == b2r && idx > b2i)) { b2r = r; b2i = idx; }
+            }
+        }
+        MCF_TEAM_BARRIER();
+        const bool found = acc->jpos >= 0;
+        if (lane == 0) acc->rounds += 1;
+        MCF_TEAM_BARRIER();  // nobody may start the next chunk's atomics before everybody has read jpos
+        if (found) break;
+        if (lo <= 0) { failed = true; break; }  // position 0 is the root, a common ancestor: cannot happen
+        top = lo;
+    }
+    if (failed) {
+        if (lane == 0) c->status = MCF_INTERNAL_ERROR;
+        return;
+    }
+    if (b1i >= 0) MCF_ATOMIC_MIN64(&acc->r1, b1r);
+    if (b2i >= 0) MCF_ATOMIC_MIN64(&acc->r2, b2r);
+    MCF_TEAM_BARRIER();
+    if (b1i >= 0 && b1r == acc->r1) MCF_ATOMIC_MIN32(&acc->i1, b1i);
+    if (b2i >= 0 && b2r == acc->r2) MCF_ATOMIC_MAX32(&acc->i2, b2i);
+    MCF_TEAM_BARRIER();
+    if (lane == 0) {
+        // merge with what the climb found: its elements have the lower path indices
+        if (acc->i1 != INT32_MAX && acc->r1 < cy->d1) { cy->d1 = acc->r1; cy->k1 = acc->i1; }
+        if (acc->i2 >= 0 && acc->r2 <= cy->d2) { cy->d2 = acc->r2; cy->k2 = acc->i2; }
+        const int32_t jn = ord[acc->jpos];
+        const McfNode rj = v.node[jn];
+        cy->n1 = base1 + du - rj.depth;
+        cy->n2 = base2 + dw - rj.depth;
+        cy->u = jn; cy->w = jn;
+        cy->ru = rj; cy->rw = rj;
+        c->scans += 1;
+        c->scan_rounds += acc->rounds;
+    }
+}
+
+// Step 3 (one lane): ratio-test decision + everything the finish / apply passes need to know.
+MCF_HD void mcf_pivot_decide(const McfView& v, const McfCycle& cy) {
+    McfCtx* c = v.ctx;
+    const int32_t e = c->pv_e, s = c->pv_s, first = c->pv_first, second = c->pv_second;
+    const int64_t rc = c->pv_rc;
+    const int64_t d1 = cy.d1, d2 = cy.d2;
+    const int32_t k1 = cy.k1, k2 = cy.k2, n1 = cy.n1, n2 = cy.n2;
+    const McfNode ru = cy.ru;  // joined: ru == rw == the join's record
     const int64_t de = v.arcw[e].cap;  // residual of the entering arc in its push direction
     int32_t result;
     int64_t delta;
@@ -343,7 +523,9 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     c->pv_k = k;
     c->pv_vin = v_in;
     c->pv_leave = rq.pred >> 1;
-    c->pv_leave_state = result == 1 ? ls1 : ls2;
+    // state the leaving arc takes: the first side is walked against the flow (an up arc ends empty),
+    // the second side with it (an up arc ends full)
+    c->pv_leave_state = result == 1 ? ((rq.pred & 1) ? 1 : -1) : ((rq.pred & 1) ? -1 : 1);
     c->pv_tail_in_t2 = tail_in_t2 ? 1 : 0;
     c->sigma = tail_in_t2 ? -rc : rc;  // potential shift that zeroes the entering arc's reduced cost
 
@@ -373,6 +555,21 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     c->subtree_nodes += S;
     c->nodes_moved += c->hi - c->lo;
     c->stage = 2;
+}
+
+// The whole cycle search + decision for single-threaded callers (CPU emulation): climb within the
+// budget, then -- when the view carries psz[] -- the scan as a team of one.
+MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
+    if (!mcf_pivot_begin(v, best_key, best_arc, rule)) return;
+    McfCycle cy;
+    mcf_cycle_init(v, &cy);
+    if (!mcf_pivot_climb(v, &cy, v.psz[0] ? v.ctx->climb_budget : INT32_MAX)) return;
+    if (cy.u != cy.w) {
+        McfScanAcc acc;
+        mcf_pivot_scan(v, &cy, &acc, 0, 1);
+        if (v.ctx->status != MCF_RUNNING) return;
+    }
+    mcf_pivot_decide(v, cy);
 }
 
 MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
@@ -412,8 +609,18 @@ MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
     }
     // subtree sizes outside T2: the old ancestors of q lose S, v_in and its ancestors gain S
     // (join and above keep their size)
-    for (int32_t i = k + 1 + lane; i < nstem_side; i += nlanes) v.node[stem[i]].size = srec[i].size - S;
-    for (int32_t i = lane; i < nother; i += nlanes) v.node[other[i]].size = orec[i].size + S;
+    // The position-space copies are written at the OLD position into BOTH buffers: a node outside the
+    // affected range keeps its position (both buffers must agree there), one inside is moved -- together
+    // with this value -- by the apply pass, which reads psz[cur] and overwrites psz[cur ^ 1].
+    const int32_t* pcur0 = c->cur ? v.posbuf[1] : v.posbuf[0];
+    for (int32_t i = k + 1 + lane; i < nstem_side; i += nlanes) {
+        v.node[stem[i]].size = srec[i].size - S;
+        if (v.psz[0]) { const int32_t p = pcur0[stem[i]]; v.psz[0][p] = srec[i].size - S; v.psz[1][p] = srec[i].size - S; }
+    }
+    for (int32_t i = lane; i < nother; i += nlanes) {
+        v.node[other[i]].size = orec[i].size + S;
+        if (v.psz[0]) { const int32_t p = pcur0[other[i]]; v.psz[0][p] = orec[i].size + S; v.psz[1][p] = orec[i].size + S; }
+    }
 
     // re-root T2 at u_in: reverse the stem and emit the block permutation.
     // Old layout: block(s_i) = [p_i, p_i + z_i), nested, s_k = q.  New layout: block(s_0), then
@@ -445,6 +652,7 @@ MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
             v.seg[2 * i] = McfSeg{dst + left, pp + rp.size, right, dd};
         }
         v.node[stem[i]] = nr;
+        if (v.psz[0]) { v.psz[0][p] = nr.size; v.psz[1][p] = nr.size; }  // moved to its new position by the apply pass
     }
 }
 
@@ -483,6 +691,8 @@ MCF_HD void mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
     const int32_t* src = c.cur ? v.order[1] : v.order[0];
     int32_t* dst = c.cur ? v.order[0] : v.order[1];
     int32_t* pnext = c.cur ? v.posbuf[0] : v.posbuf[1];
+    const int32_t* zsrc = c.cur ? v.psz[1] : v.psz[0];
+    int32_t* zdst = c.cur ? v.psz[0] : v.psz[1];
     if (j >= c.lo && j < c.hi) {
         bool in_t2;
         int32_t dd;
@@ -490,6 +700,7 @@ MCF_HD void mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
         const int32_t nd = src[i];
         dst[j] = nd;
         pnext[nd] = j;
+        if (zsrc) zdst[j] = zsrc[i];  // subtree sizes travel with their nodes (the finish pass ran before)
         if (in_t2) {
             v.pi[nd] += c.sigma;
             if (dd) v.node[nd].depth += dd;
@@ -498,5 +709,6 @@ MCF_HD void mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
         const int32_t nd = src[j];
         dst[j] = nd;  // catch up on what the previous apply changed in the other copy
         pnext[nd] = j;
+        if (zsrc) zdst[j] = zsrc[j];
     }
 }

@@ -39,7 +39,9 @@
 namespace {
 
 constexpr int kPriceThreads = 256;
-constexpr int kPivotThreads = 256;
+constexpr int kPivotThreads = 1024;  // one workgroup: final arg-max, cycle search (climb by one lane / scan by all), finish
+constexpr int kReduceThreads = 256;
+constexpr int kScanMaxNodes = 1 << 20;  // beyond this the position-space sizes are not kept: the cycle is always climbed
 constexpr int kApplyThreads = 256;
 constexpr int kMaxPriceBlocks = 2048;  // 8 workgroups per CU on 256 CUs
 constexpr int kMaxApplyBlocks = 512;
@@ -307,14 +309,14 @@ __global__ __launch_bounds__(kRcupdThreads) void k_update(McfView v) {
 }
 
 // ------------------------------------------------------------------ k_reduce (multi-GPU: local best -> 16 bytes)
-__global__ __launch_bounds__(kPivotThreads) void k_reduce(const McfCand* __restrict__ cand, int ncand,
-                                                           McfCand* __restrict__ out) {
+__global__ __launch_bounds__(kReduceThreads) void k_reduce(const McfCand* __restrict__ cand, int ncand,
+                                                            McfCand* __restrict__ out) {
     int64_t key = 0, arc = -1;
-    for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
+    for (int i = threadIdx.x; i < ncand; i += kReduceThreads) {
         const McfCand cd = cand[i];
         if (mcf_cand_better(cd.key, cd.arc, key, arc)) { key = cd.key; arc = cd.arc; }
     }
-    block_argmax<kPivotThreads>(key, arc);
+    block_argmax<kReduceThreads>(key, arc);
     if (threadIdx.x == 0) *out = McfCand{key, arc};
 }
 
@@ -337,6 +339,9 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView v, const McfCan
         if (mcf_cand_better(kk, cd.arc, key, arc)) { key = kk; arc = cd.arc; }
     }
     block_argmax<kPivotThreads>(key, arc);
+    __shared__ McfCycle s_cy;
+    __shared__ McfScanAcc s_acc;
+    __shared__ int s_go;  // 0 = nothing to pivot on, 1 = the climb reached the join, 2 = the scan has to finish the cycle
     if (threadIdx.x == 0) {
         McfCtx* c = v.ctx;
         if (c->pivots < c->max_pivots) {
@@ -352,8 +357,18 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView v, const McfCan
             }
             c->arcs_priced += priced;
         }
-        mcf_pivot_walk(v, key, arc, rule);   // sequential: O(cycle) dependent loads
+        int go = 0;
+        if (mcf_pivot_begin(v, key, arc, rule)) {
+            mcf_cycle_init(v, &s_cy);
+            // sequential part: at most climb_budget dependent round trips
+            if (mcf_pivot_climb(v, &s_cy, v.psz[0] ? c->climb_budget : INT32_MAX)) go = s_cy.u == s_cy.w ? 1 : 2;
+        }
+        s_go = go;
     }
+    __syncthreads();
+    const int go = s_go;
+    if (go == 2) mcf_pivot_scan(v, &s_cy, &s_acc, threadIdx.x, kPivotThreads);  // the whole workgroup, barriers inside
+    if (go && threadIdx.x == 0 && v.ctx->status == MCF_RUNNING) mcf_pivot_decide(v, s_cy);
     __syncthreads();
     mcf_pivot_finish(v, threadIdx.x, kPivotThreads);  // array updates, one path element per lane
 }
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
 // mcf_apply_one) and copies the state back.  Same arc sets, same tie rule, same core functions
 // as the three-kernel path, so the pivot sequence is identical.
 struct SmallLayout {
-    uint32_t tail, head, cost, orig, state, weight, arcw, pi, node, order0, order1, pos0, pos1, path1, path2, rec1, rec2, seg, ctx, total;
+    uint32_t tail, head, cost, orig, state, weight, arcw, pi, node, order0, order1, pos0, pos1, psz0, psz1, path1, path2, rec1, rec2, seg, ctx, total;
 };
 
 constexpr int kSmallThreads = 1024;
@@ -435,6 +450,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     v.ctx = reinterpret_cast<McfCtx*>(smem + L.ctx);
     v.posbuf[0] = reinterpret_cast<int32_t*>(smem + L.pos0);
     v.posbuf[1] = reinterpret_cast<int32_t*>(smem + L.pos1);
+    v.psz[0] = g.psz[0] ? reinterpret_cast<int32_t*>(smem + L.psz0) : nullptr;
+    v.psz[1] = g.psz[0] ? reinterpret_cast<int32_t*>(smem + L.psz1) : nullptr;
 
     copy_words(smem + L.tail, g.tail, m_pad4);
     copy_words(smem + L.head, g.head, m_pad4);
@@ -449,6 +466,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     copy_words(smem + L.order1, g.order[1], N * 4u);
     copy_words(smem + L.pos0, g.posbuf[0], N * 4u);
     copy_words(smem + L.pos1, g.posbuf[1], N * 4u);
+    if (g.psz[0]) { copy_words(smem + L.psz0, g.psz[0], N * 4u); copy_words(smem + L.psz1, g.psz[1], N * 4u); }
     copy_words(smem + L.ctx, g.ctx, (uint32_t)sizeof(McfCtx));
     __syncthreads();
     STAMP(0);
@@ -473,6 +491,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     // those 8 arcs.  The list survives between launches in `list` (global).
     const bool listing = rule == MCF_RULE_CANDIDATE_LIST;
     __shared__ int64_t s_lk[MCF_NUM_BUCKETS], s_la[MCF_NUM_BUCKETS];
+    __shared__ McfCycle s_cy;
+    __shared__ McfScanAcc s_acc;
+    __shared__ int s_go;
     if (listing && threadIdx.x < MCF_NUM_BUCKETS) { s_lk[threadIdx.x] = list[threadIdx.x].key; s_la[threadIdx.x] = list[threadIdx.x].arc; }
     __syncthreads();
     for (;;) {
@@ -537,8 +558,17 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
                 for (int x = 0; x < MCF_NUM_BUCKETS; ++x) priced += s_hi[row + x] - s_lo[row + x];
                 c->arcs_priced += minor ? MCF_NUM_BUCKETS : priced;
             }
-            mcf_pivot_walk(v, key, arc, rule);
+            int go = 0;
+            if (mcf_pivot_begin(v, key, arc, rule)) {
+                mcf_cycle_init(v, &s_cy);
+                if (mcf_pivot_climb(v, &s_cy, v.psz[0] ? c->climb_budget : INT32_MAX)) go = s_cy.u == s_cy.w ? 1 : 2;
+            }
+            s_go = go;
         }
+        __syncthreads();
+        const int go = s_go;
+        if (go == 2) mcf_pivot_scan(v, &s_cy, &s_acc, threadIdx.x, kSmallThreads);
+        if (go && threadIdx.x == 0 && c->status == MCF_RUNNING) mcf_pivot_decide(v, s_cy);
         STAMP(3);
         __syncthreads();
         mcf_pivot_finish(v, threadIdx.x, kSmallThreads);
@@ -570,6 +600,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     copy_words(g.order[1], smem + L.order1, N * 4u);
     copy_words(g.posbuf[0], smem + L.pos0, N * 4u);
     copy_words(g.posbuf[1], smem + L.pos1, N * 4u);
+    if (g.psz[0]) { copy_words(g.psz[0], smem + L.psz0, N * 4u); copy_words(g.psz[1], smem + L.psz1, N * 4u); }
     copy_words(g.ctx, smem + L.ctx, (uint32_t)sizeof(McfCtx));
     if (listing && threadIdx.x < MCF_NUM_BUCKETS) list[threadIdx.x] = McfCand{s_lk[threadIdx.x], s_la[threadIdx.x]};
 #ifdef MCF_STAMPS
@@ -610,7 +641,7 @@ struct mcf_handle {
     int32_t *d_order0 = nullptr, *d_order1 = nullptr, *d_path1 = nullptr, *d_path2 = nullptr;
     McfNode *d_rec1 = nullptr, *d_rec2 = nullptr;
     int64_t *d_rcache = nullptr, *d_adj_off = nullptr, *d_adj = nullptr;
-    int32_t *d_pos0 = nullptr, *d_pos1 = nullptr;
+    int32_t *d_pos0 = nullptr, *d_pos1 = nullptr, *d_psz0 = nullptr, *d_psz1 = nullptr;
     bool rcached = false;     // large instance: resident reduced costs + k_rcupd
     int rcupd_blocks = 1;
     McfSeg* d_seg = nullptr;
@@ -623,6 +654,7 @@ struct mcf_handle {
     McfView view{};
     int price_blocks = 1;
     int apply_blocks = 1;
+    int32_t climb_budget = INT32_MAX;  // round trips the cycle climb may take before the scan takes over
     bool small = false;       // whole instance fits in LDS: fused single-workgroup pivot loop
     SmallLayout small_layout{};
     int64_t shard = 0, shards = 1;
@@ -676,6 +708,10 @@ int upload_image(mcf_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->d_order1, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_pos0, im.pos.data(), im.pos.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_pos1, im.pos.data(), im.pos.size() * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->d_psz0) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_psz0, im.psize.data(), im.psize.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_psz1, im.psize.data(), im.psize.size() * 4, hipMemcpyHostToDevice, h->stream));
+    }
     if (h->rcached)
         HIP_TRY(h, hipMemcpyAsync(h->d_rcache, im.rcache.data(), im.m_pad * 8, hipMemcpyHostToDevice, h->stream));
     McfCtx c;
@@ -689,6 +725,7 @@ int upload_image(mcf_handle* h) {
     c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
     if (c.num_blocks < 1) c.num_blocks = 1;
     c.minor_cap = mcf_minor_cap(h->price_blocks);
+    c.climb_budget = h->climb_budget;
     *h->h_ctx = c;
     HIP_TRY(h, hipMemcpyAsync(h->d_ctx, h->h_ctx, sizeof(McfCtx), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -805,6 +842,8 @@ void free_all(mcf_handle* h) {
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
+    (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1);
+    (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
     if (h->h_one) (void)hipHostFree(h->h_one);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -894,6 +933,11 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     if ((e = dalloc(&h->d_order1, N)) != hipSuccess) return fail("hipMalloc order", e);
     if ((e = dalloc(&h->d_pos0, N)) != hipSuccess) return fail("hipMalloc pos", e);
     if ((e = dalloc(&h->d_pos1, N)) != hipSuccess) return fail("hipMalloc pos", e);
+    const bool scan_ok = opt.cycle_scan >= 0 && im.n_nodes <= kScanMaxNodes;  // -1: never scan
+    if (scan_ok) {
+        if ((e = dalloc(&h->d_psz0, N)) != hipSuccess) return fail("hipMalloc psz", e);
+        if ((e = dalloc(&h->d_psz1, N)) != hipSuccess) return fail("hipMalloc psz", e);
+    }
     if ((e = dalloc(&h->d_path1, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_path2, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_rec1, N)) != hipSuccess) return fail("hipMalloc rec", e);
@@ -916,6 +960,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     v.arcw = h->d_arcw; v.pi = h->d_pi; v.node = h->d_node;
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
     v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
+    v.psz[0] = h->d_psz0; v.psz[1] = h->d_psz1;
     v.path1 = h->d_path1; v.path2 = h->d_path2; v.rec1 = h->d_rec1; v.rec2 = h->d_rec2; v.seg = h->d_seg; v.ctx = h->d_ctx;
 
     {
@@ -928,11 +973,12 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         L.state = take(mp); L.weight = take(opt.rule == MCF_RULE_DEVEX_BLOCK ? mp * 4 : 0);
         L.arcw = take((uint64_t)im.arcw.size() * 16); L.pi = take(Nn * 8); L.node = take(Nn * 16);
         L.order0 = take(Nn * 4); L.order1 = take(Nn * 4); L.pos0 = take(Nn * 4); L.pos1 = take(Nn * 4);
+        L.psz0 = take(scan_ok ? Nn * 4 : 0); L.psz1 = take(scan_ok ? Nn * 4 : 0);
         L.path1 = take(Nn * 4); L.path2 = take(Nn * 4);
         L.rec1 = take(Nn * 16); L.rec2 = take(Nn * 16);
         L.seg = take((2 * Nn + 2) * sizeof(McfSeg)); L.ctx = take(sizeof(McfCtx));
         L.total = off;
-        const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 104 + 4096;
+        const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 112 + 4096;
         h->small = !opt.no_fused && !opt.profile && h->shards == 1 && need < 150 * 1024 && L.total <= 158 * 1024;
         if (h->small) {
             hipError_t fe = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small),
@@ -940,6 +986,13 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
             if (fe != hipSuccess) h->small = false;  // fall back to the three-kernel GPU path
         }
     }
+    // cycle search: how many round trips the one-lane climb takes before the workgroup-wide scan over
+    // preorder positions finishes the cycle (auto: the LDS loop scans at once -- a barrier costs less
+    // than a dependent LDS round trip there; the global path climbs a few steps first because most
+    // netgen cycles close within them)
+    if (!scan_ok) h->climb_budget = INT32_MAX;
+    else if (opt.cycle_scan > 0) h->climb_budget = opt.cycle_scan - 1;
+    else h->climb_budget = h->small ? 0 : 8;
     // resident reduced costs for everything that does not take the fused LDS path
     h->rcached = !h->small && !opt.no_rcache && im.m > 0;
     if (h->rcached) {
@@ -1085,6 +1138,7 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
         h->stats.unbounded_arc = c.unbounded_arc >= 0 ? im.orig[c.unbounded_arc] : -1;
         h->stats.artificial_flow = r.artificial_flow;
         h->stats.pricing_mode = h->small ? 2 : (h->rcached ? 1 : 0);
+        h->stats.cycle_scans = c.scans; h->stats.scan_rounds = c.scan_rounds;
         h->stats.unbounded_rc = 0;
         if (c.status == MCF_UNBOUNDED && c.unbounded_arc >= 0) {
             std::vector<int64_t> pi(im.n_nodes);
@@ -1128,7 +1182,7 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
                 hipLaunchKernelGGL((k_price<MCF_RULE_DANTZIG, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux);
         }
     }
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, h->stream, h->d_cand_aux, h->price_blocks, h->d_one);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kReduceThreads), 0, h->stream, h->d_cand_aux, h->price_blocks, h->d_one);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(&h->d_ctx->status, &saved, 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_one, h->d_one, sizeof(McfCand), hipMemcpyDeviceToHost, h->stream));
@@ -1152,7 +1206,7 @@ int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int32_t rule = h->opt.rule;
     launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kPivotThreads), 0, s, h->d_cand, h->price_blocks,
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kReduceThreads), 0, s, h->d_cand, h->price_blocks,
                        reinterpret_cast<McfCand*>(cand_out_dev));
     HIP_TRY(h, hipGetLastError());
     return MCF_OK;
@@ -1239,7 +1293,7 @@ int mcf_time_copy(int32_t device, int64_t bytes, int32_t reps, double* ms_per_co
 }
 
 int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos, int32_t* order,
-                 int8_t* state, int64_t* potential_with_root, int32_t* depth) {
+                 int8_t* state, int64_t* potential_with_root, int32_t* depth, int32_t* psize) {
     if (!h) return MCF_E_BAD_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = read_ctx(h, h->stream);
@@ -1259,6 +1313,10 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
     const int cur = h->h_ctx->cur ^ (h->h_ctx->pending_flip ? 1 : 0);
     if (order) HIP_TRY(h, hipMemcpy(order, cur ? h->d_order1 : h->d_order0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
     if (pos) HIP_TRY(h, hipMemcpy(pos, cur ? h->d_pos1 : h->d_pos0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
+    if (psize) {
+        if (h->d_psz0) HIP_TRY(h, hipMemcpy(psize, cur ? h->d_psz1 : h->d_psz0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
+        else for (int32_t v = 0; v < im.n_nodes; ++v) psize[v] = -1;  // not kept for this handle
+    }
     if (state) {
         std::vector<int8_t> st(im.m_pad);
         HIP_TRY(h, hipMemcpy(st.data(), h->d_state, st.size(), hipMemcpyDeviceToHost));

@@ -32,6 +32,7 @@ struct McfHostImage {
     std::vector<McfNode> node;              // [n_nodes]
     std::vector<int32_t> order;             // [n_nodes]
     std::vector<int32_t> pos;               // [n_nodes] preorder position of every node (inverse of order)
+    std::vector<int32_t> psize;             // [n_nodes] subtree size of the node at each POSITION
     std::vector<int64_t> supply;            // [n]
     // resident reduced costs + node->arc adjacency (mcf_build_rcache)
     std::vector<int64_t> rcache;            // [m_pad]
@@ -129,6 +130,8 @@ inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, co
     im.node.assign(im.n_nodes, McfNode{-1, -1, 1, 0});
     im.order.assign(im.n_nodes, 0);
     im.pos.assign(im.n_nodes, 0);
+    im.psize.assign(im.n_nodes, 1);
+    im.psize[0] = im.n_nodes;  // the root sits at position 0
     im.node[root] = McfNode{-1, -1, im.n_nodes, 0};
     im.order[0] = root;
     im.pos[root] = 0;

@@ -51,7 +51,7 @@ class McfOptions(ctypes.Structure):
         ("batch_pivots", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("profile", ctypes.c_int32),
         ("block_size", ctypes.c_int64), ("shard_rank", ctypes.c_int64), ("shard_count", ctypes.c_int64),
         ("price_blocks", ctypes.c_int32), ("no_fused", ctypes.c_int32), ("no_rcache", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("cycle_scan", ctypes.c_int32),
     ]
 
 
@@ -64,6 +64,7 @@ class McfStats(ctypes.Structure):
         ("pivot_ms", ctypes.c_double), ("apply_ms", ctypes.c_double), ("price_launches", ctypes.c_int64),
         ("pivot_launches", ctypes.c_int64), ("apply_launches", ctypes.c_int64), ("price_bytes", ctypes.c_int64),
         ("artificial_flow", ctypes.c_int64), ("pricing_mode", ctypes.c_int64),
+        ("cycle_scans", ctypes.c_int64), ("scan_rounds", ctypes.c_int64),
     ]
 
     def as_dict(self) -> dict:
@@ -103,7 +104,7 @@ def load_library():
     lib.mcf_set_max_pivots.argtypes = [vp, ctypes.c_int64]
     lib.mcf_time_pricing.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     lib.mcf_time_copy.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
-    lib.mcf_get_tree.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i8p, i64p, i32p]
+    lib.mcf_get_tree.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i8p, i64p, i32p, i32p]
     lib.mcf_get_reduced_costs.argtypes = [vp, i64p, i32p]
     lib.mcf_dimacs_scan.argtypes = [ctypes.c_char_p, i64p, i64p, ctypes.c_char_p, ctypes.c_int32]
     lib.mcf_dimacs_load.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, i64p,
@@ -146,7 +147,7 @@ class McfEngine:
     def __init__(self, n: int, tail, head, cost, cap, supply, rule: int = RULE_DANTZIG, block_size: int = 0,
                  batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
                  shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
-                 resident_rc: bool = True):
+                 resident_rc: bool = True, cycle_scan: int = 0):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -174,6 +175,7 @@ class McfEngine:
         opt.price_blocks = int(price_blocks)
         opt.no_fused = 0 if fused else 1
         opt.no_rcache = 0 if resident_rc else 1
+        opt.cycle_scan = int(cycle_scan)
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule
@@ -262,13 +264,14 @@ class McfEngine:
 
     def tree(self) -> dict:
         N = self.n + 1
-        parent, pred, size, pos, order, depth = (np.zeros(N, dtype=np.int32) for _ in range(6))
+        parent, pred, size, pos, order, depth, psize = (np.zeros(N, dtype=np.int32) for _ in range(7))
         state = np.zeros(max(self.m, 1), dtype=np.int8)
         pi = np.zeros(N, dtype=np.int64)
         i32 = ctypes.c_int32
         self._check(self._lib.mcf_get_tree(self._h, _p(parent, i32), _p(pred, i32), _p(size, i32), _p(pos, i32),
-                                           _p(order, i32), _p(state, ctypes.c_int8), _p(pi, ctypes.c_int64), _p(depth, i32)))
-        return {"parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order, "depth": depth,
+                                           _p(order, i32), _p(state, ctypes.c_int8), _p(pi, ctypes.c_int64), _p(depth, i32),
+                                           _p(psize, i32)))
+        return {"parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order, "depth": depth, "psize": psize,
                 "state": state[: self.m], "pi": pi}
 
     def reduced_costs(self):

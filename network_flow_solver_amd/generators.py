@@ -210,6 +210,8 @@ def named_instance(name: str) -> ArcSoA:
         "gridgen_8_08a": lambda: gridgen_style(16, 16, seed=1, name="gridgen_8_08a(synthetic)"),
         "gridgen_8_14a": lambda: gridgen_style(128, 128, seed=1, name="gridgen_8_14a(synthetic)"),
         "goto_8_08a": lambda: goto_style(16, 16, seed=1, name="goto_8_08a(synthetic)"),
+        "goto_8_12a": lambda: goto_style(64, 64, seed=1, name="goto_8_12a(synthetic)"),
+        "goto_8_14a": lambda: goto_style(128, 128, seed=1, name="goto_8_14a(synthetic)"),
         "goto_8_16a": lambda: goto_style(256, 256, seed=1, name="goto_8_16a(synthetic)"),
         "netgen_1m_16m": lambda: netgen_style(1 << 20, 16 << 20, seed=1, name="netgen_1M_16M(synthetic)"),
     }

@@ -20,7 +20,7 @@ namespace {
 
 struct Emul {
     McfHostImage im;
-    std::vector<int32_t> order1, path1, path2, pos1;
+    std::vector<int32_t> order1, path1, path2, pos1, psz1;
     std::vector<McfNode> rec1, rec2;
     std::vector<McfSeg> seg;
     McfCtx ctx;
@@ -67,6 +67,9 @@ void bind(Emul& e) {
     v.adj = nullptr;
     v.posbuf[0] = im.pos.data();
     v.posbuf[1] = e.pos1.data();
+    e.psz1 = im.psize;
+    v.psz[0] = im.psize.data();
+    v.psz[1] = e.psz1.data();
 }
 
 // scalar stand-in for the pricing kernel: shard r of G, Devex block = ctx.block_index of
@@ -141,7 +144,8 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
                const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int64_t max_pivots,
                int32_t* status, int64_t* objective_hi_lo, int64_t* flow, int64_t* potential, int8_t* in_tree,
                int64_t* stats /*[12]*/, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
-               int32_t* order, int64_t* trace_arcs, int64_t trace_cap, int32_t bucketed, int32_t* depth) {
+               int32_t* order, int64_t* trace_arcs, int64_t trace_cap, int32_t bucketed, int32_t* depth, int32_t* psize,
+               int32_t climb_budget /* < 0: always climb */, int64_t* scan_stats /*[2] or null*/) {
     Emul e;
     e.rule = rule;
     int err = 0;
@@ -151,6 +155,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     McfCtx& c = e.ctx;
     c.max_pivots = max_pivots < 0 ? (20 * (m + n) > 100 ? 20 * (m + n) : 100) : max_pivots;
     init_blocks(e, block_size);
+    c.climb_budget = climb_budget < 0 ? INT32_MAX : climb_budget;
     const auto t0 = std::chrono::steady_clock::now();
     int64_t ntrace = 0;
     while (c.status == MCF_RUNNING) {
@@ -187,6 +192,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     stats[7] = c.unbounded_arc >= 0 ? e.im.orig[c.unbounded_arc] : -1;
     stats[8] = r.artificial_flow; stats[9] = (int64_t)(secs * 1e9);
     stats[10] = c.minor_pivots; stats[11] = c.major_sweeps;
+    if (scan_stats) { scan_stats[0] = c.scans; scan_stats[1] = c.scan_rounds; }
     const int32_t* ord = e.view.order[c.cur];
     const int32_t* pcur = e.view.posbuf[c.cur];
     for (int32_t v = 0; v <= n; ++v) {
@@ -198,6 +204,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         if (size) size[v] = e.im.node[v].size;
         if (pos) pos[v] = pcur[v];
         if (depth) depth[v] = e.im.node[v].depth;
+        if (psize) psize[v] = e.view.psz[c.cur][v];
         if (order) order[v] = ord[v];
     }
     return 0;
@@ -216,6 +223,7 @@ void* emul_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head
     bind(*e);
     McfCtx& c = e->ctx;
     c.max_pivots = INT64_MAX;
+    c.climb_budget = INT32_MAX;
     init_blocks(*e, block_size);
     return e;
 }

@@ -68,7 +68,7 @@ def strategies_agree(case: dict) -> bool:
     return all("flows" in v for v in e.values()) and len({json.dumps(v["flows"]) for v in e.values()}) == 1
 
 
-def check_tree_invariants(n: int, parent, size, pos, order, depth=None):
+def check_tree_invariants(n: int, parent, size, pos, order, depth=None, psize=None):
     """Preorder-array spanning tree: order is a permutation, pos inverts it, every subtree is
     the contiguous block [pos, pos+size) nested in its parent's, sizes add up."""
     N = n + 1
@@ -81,6 +81,8 @@ def check_tree_invariants(n: int, parent, size, pos, order, depth=None):
         assert pos[p] < pos[v] and pos[v] + size[v] <= pos[p] + size[p], f"block of {v} not nested in {p}"
         child_sum[p] += size[v]
     assert np.array_equal(child_sum + 1, np.asarray(size, dtype=np.int64))
+    if psize is not None:  # position-space sizes: what the block-wide cycle scan tests ancestry with
+        assert np.array_equal(np.asarray(psize)[np.asarray(pos)], np.asarray(size))
     if depth is not None:  # the depth-balanced cycle walk relies on these
         assert depth[n] == 0 and all(depth[v] == depth[parent[v]] + 1 for v in range(n))
 

@@ -16,7 +16,7 @@ def test_integer_engine_reaches_reference_optimum(entry, inst, rule):
     res = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
     assert res["status"] == "optimal"
     assert res["objective"] == int(round(exp["objective"]))          # bit-exact integer objective
-    check_tree_invariants(inst.n, res["parent"], res["size"], res["pos"], res["order"], res["depth"])
+    check_tree_invariants(inst.n, res["parent"], res["size"], res["pos"], res["order"], res["depth"], res["psize"])
     rc = check_optimality(inst, res["flow"], res["potential"])
     if optimum_is_unique(inst, res["flow"], res["in_tree"], rc):
         got = {(int(inst.tail[i]), int(inst.head[i])): float(res["flow"][i]) for i in range(inst.m) if res["flow"][i]}
@@ -27,7 +27,7 @@ def test_tree_invariants_hold_after_every_pivot():
     _, inst = load_synthetic()[0]
     for cap in range(1, 140):
         res = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0, max_pivots=cap)
-        check_tree_invariants(inst.n, res["parent"], res["size"], res["pos"], res["order"], res["depth"])
+        check_tree_invariants(inst.n, res["parent"], res["size"], res["pos"], res["order"], res["depth"], res["psize"])
         if res["status"] == "optimal":
             break
     assert res["status"] == "optimal"
@@ -69,3 +69,30 @@ def test_candidate_list_sweeps_far_less_than_dantzig():
     assert c["major_sweeps"] + c["minor_pivots"] >= c["pivots"] and c["minor_pivots"] > c["pivots"] // 2
     assert c["major_sweeps"] < d["pivots"] // 2 and c["arcs_priced"] < d["arcs_priced"] // 2
     assert c["pivots"] < 1.3 * d["pivots"]
+
+
+@pytest.mark.parametrize("entry,inst", load_synthetic(), ids=lambda x: x["name"] if isinstance(x, dict) else "")
+@pytest.mark.parametrize("budget", [0, 3], ids=["scan_only", "climb3_then_scan"])
+def test_cycle_scan_reproduces_the_climb(entry, inst, budget):
+    """mcf_pivot_scan (cycle found by a sweep over preorder positions with the position-space subtree
+    sizes) must hand the ratio test exactly what the pointer-chasing climb hands it: same entering arcs,
+    same leaving arcs, hence the same pivot sequence, flows, potentials and tree."""
+    kw = dict(rule=0, trace=100000)
+    a = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, climb_budget=-1, **kw)
+    b = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, climb_budget=budget, **kw)
+    assert a["scans"] == 0 and b["scans"] > 0
+    assert b["pivots"] == a["pivots"] and np.array_equal(a["trace"], b["trace"])
+    for key in ("flow", "potential", "parent", "pred_arc", "size", "pos", "order", "depth", "psize"):
+        assert np.array_equal(a[key], b[key]), key
+    assert b["degenerate"] == a["degenerate"] and b["cycle_arcs"] == a["cycle_arcs"]
+    check_tree_invariants(inst.n, b["parent"], b["size"], b["pos"], b["order"], b["depth"], b["psize"])
+
+
+def test_cycle_scan_on_devex_and_candidate_list_rules():
+    _, inst = load_synthetic()[3]
+    for rule in (1, 2):
+        a = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, trace=100000)
+        b = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, trace=100000,
+                              climb_budget=0)
+        assert np.array_equal(a["trace"], b["trace"]) and np.array_equal(a["flow"], b["flow"])
+        assert b["objective"] == a["objective"] and b["scans"] > 0

@@ -38,7 +38,7 @@ def test_synthetic_goldens_exact(gpu_engine_module, entry, inst, rule):
     res, tree = _solve(gpu_engine_module, inst, rule)
     assert res.status == "optimal"
     assert res.objective == int(round(exp["objective"]))
-    check_tree_invariants(inst.n, tree["parent"], tree["size"], tree["pos"], tree["order"], tree["depth"])
+    check_tree_invariants(inst.n, tree["parent"], tree["size"], tree["pos"], tree["order"], tree["depth"], tree["psize"])
     rc = check_optimality(inst, res.flow, res.potential)
     if optimum_is_unique(inst, res.flow, res.in_tree, rc):
         got = {(int(inst.tail[i]), int(inst.head[i])): float(res.flow[i]) for i in range(inst.m) if res.flow[i]}
@@ -92,6 +92,47 @@ def test_resident_reduced_costs_stay_exact(gpu_engine_module, rule):
     assert res.status == ref.status == "optimal" and res.stats["pivots"] == ref.stats["pivots"]
     assert np.array_equal(res.flow, ref.flow) and np.array_equal(res.potential, ref.potential)
     assert np.array_equal(tree["order"], rtree["order"]) and res.stats["arcs_priced"] == ref.stats["arcs_priced"]
+
+
+@pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
+@pytest.mark.parametrize("idx,fused", [(3, True), (6, True), (6, False), (7, True)],
+                         ids=["netgen256_fused_lds", "goto256_fused_lds", "goto256_kernel_path", "netgen1024_kernel_path"])
+def test_cycle_scan_equals_cycle_climb(gpu_engine_module, idx, fused, rule):
+    """The workgroup-wide scan over preorder positions (mcf_pivot_scan: ancestors found with the
+    position-space subtree sizes, ratio test by team-wide atomics) against the one-lane parent-pointer
+    climb: scan only, climb 3 then scan, climb only -- identical pivot sequence and tree, and identical
+    to the CPU emulation."""
+    _, inst = load_synthetic()[idx]
+    runs = {cs: _solve(gpu_engine_module, inst, rule, cycle_scan=cs, fused=fused) for cs in (-1, 1, 4)}
+    r0, t0 = runs[-1]
+    assert r0.stats["cycle_scans"] == 0 and (t0["psize"] == -1).all()      # sizes are not even kept
+    em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, climb_budget=0)
+    assert runs[1][0].stats["cycle_scans"] == em["scans"] > 0
+    for cs in (1, 4):
+        r, t = runs[cs]
+        assert r.stats["cycle_scans"] > 0
+        assert r.status == "optimal" and r.stats["pivots"] == r0.stats["pivots"] == em["pivots"]
+        assert np.array_equal(r.flow, r0.flow) and np.array_equal(r.potential, r0.potential)
+        for key in ("order", "parent", "size", "pos", "depth"):
+            assert np.array_equal(t[key], t0[key]), key
+        assert np.array_equal(t["psize"], em["psize"])
+        check_tree_invariants(inst.n, t["parent"], t["size"], t["pos"], t["order"], t["depth"], t["psize"])
+
+
+def test_cycle_scan_on_a_deep_tree(gpu_engine_module):
+    """goto-style grids grow spanning trees hundreds of arcs deep: the case the scan exists for.  Several
+    chunk rounds per scan; the result must equal the climb's bit for bit."""
+    inst = generators.goto_style(48, 48, seed=5)
+    a, ta = _solve(gpu_engine_module, inst, 0, cycle_scan=-1)
+    b, tb = _solve(gpu_engine_module, inst, 0, cycle_scan=1)
+    c, tc = _solve(gpu_engine_module, inst, 0)                            # auto
+    assert a.status == b.status == c.status == "optimal"
+    assert a.stats["pivots"] == b.stats["pivots"] == c.stats["pivots"]
+    assert b.stats["cycle_scans"] > 0 and b.stats["scan_rounds"] >= b.stats["cycle_scans"]
+    for r, t in ((b, tb), (c, tc)):
+        assert np.array_equal(r.flow, a.flow) and np.array_equal(r.potential, a.potential)
+        assert np.array_equal(t["order"], ta["order"]) and np.array_equal(t["depth"], ta["depth"])
+        check_tree_invariants(inst.n, t["parent"], t["size"], t["pos"], t["order"], t["depth"], t["psize"])
 
 
 # ------------------------------------------------------------------ golden fixtures, through the reference-shaped API
