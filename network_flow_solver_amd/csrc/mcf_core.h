@@ -39,11 +39,14 @@
 #define MCF_ATOMIC_MIN64(p, x) atomicMin(reinterpret_cast<long long*>(p), (long long)(x))
 #define MCF_ATOMIC_MIN32(p, x) atomicMin(reinterpret_cast<int*>(p), (int)(x))
 #define MCF_ATOMIC_MAX32(p, x) atomicMax(reinterpret_cast<int*>(p), (int)(x))
+#define MCF_ATOMIC_ADD32(p, x) atomicAdd(reinterpret_cast<int*>(p), (int)(x))
 #else
 #define MCF_TEAM_BARRIER() ((void)0)
 #define MCF_ATOMIC_MIN64(p, x) do { if ((int64_t)(x) < *(p)) *(p) = (int64_t)(x); } while (0)
 #define MCF_ATOMIC_MIN32(p, x) do { if ((int32_t)(x) < *(p)) *(p) = (int32_t)(x); } while (0)
 #define MCF_ATOMIC_MAX32(p, x) do { if ((int32_t)(x) > *(p)) *(p) = (int32_t)(x); } while (0)
+static inline int32_t mcf_host_fetch_add32(int32_t* p, int32_t x) { const int32_t o = *p; *p = o + x; return o; }
+#define MCF_ATOMIC_ADD32(p, x) mcf_host_fetch_add32((p), (x))
 #endif
 
 enum McfStatus : int32_t {
@@ -257,8 +260,11 @@ struct McfCycle {
 struct McfScanAcc {
     int64_t r1, r2;        // smallest residual met by the scan on either side
     int32_t i1, i2;        // path index that goes with it (side 1: lowest, side 2: highest among ties)
-    int32_t jpos;          // preorder position of the deepest common ancestor met so far, -1: none yet
-    int32_t rounds;
+    int32_t jpos[2];       // preorder position of the deepest common ancestor met so far, -1: none yet
+                           // (one slot per round parity: a round needs a single barrier)
+    int32_t nhits;         // one-sided ancestors noted so far
+    int32_t jnode;         // the join and its record (fetched while the hit pass runs)
+    McfNode join;
 };
 
 // Step 1 (one lane): bookkeeping + the entering arc.  Returns false when there is nothing to pivot on
@@ -311,7 +317,7 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
     const int32_t first = s > 0 ? v.tail[e] : v.head[e];
     const int32_t second = s > 0 ? v.head[e] : v.tail[e];
     // exact reduced cost of the entering arc (the Devex key is a merit, not a violation)
-    const int64_t rc = (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
+    const int64_t rc = v.rcache ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
 
     c->pv_e = e; c->pv_s = s; c->pv_first = first; c->pv_second = second; c->pv_rc = rc;
     return true;
@@ -382,33 +388,39 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, McfCycle* cy, int32_t budget) {
 // The node at position i is an ancestor of x (x included) iff i <= pos[x] < i + psz[i].  The nodes
 // still missing from the two paths are exactly the ancestors of cy->u that are not ancestors of
 // cy->w (first side) and vice versa; common ancestors lie at lower positions than all of them and
-// the join is the common ancestor with the highest position.  So the team sweeps the positions
-// downwards from max(pos[u], pos[w]) in chunks of nlanes * kScanK coalesced loads and stops after the
-// first chunk that holds a common ancestor.  A found ancestor a of u goes to path index
-// n1 + depth[u] - depth[a] (the depth field makes a compaction unnecessary), its record next to it,
-// exactly what the climb would have recorded.  Ratio test: every lane keeps the best residual of
-// the elements it met (side 1: lowest index among ties, side 2: highest -- the climb's `<` / `<=`);
-// two team-wide atomic minima + one tie pass combine them.  The number of dependent memory round
-// trips is ~4 per chunk whatever the length of the cycle.
-#define MCF_SCAN_K 4
-MCF_HD void mcf_pivot_scan(const McfView& v, McfCycle* cy, McfScanAcc* acc, int32_t lane, int32_t nlanes) {
+// the join is the common ancestor with the highest position.
+//   rounds:  the team sweeps the positions downwards from max(pos[u], pos[w]) in chunks of
+//            nlanes * MCF_SCAN_K coalesced 4-byte loads and stops after the first chunk that holds a
+//            common ancestor (one barrier per round; position 0, the root, ends the sweep at the latest).
+//            One-sided ancestors are only noted (position + side) in a hit list.
+//   hits:    one dense pass over the list: node id, record, arc -> three dependent loads for the whole
+//            cycle, whatever its length.  A found ancestor a of u goes to path index
+//            n1 + depth[u] - depth[a] (the depth field makes a compaction unnecessary), its record next
+//            to it -- exactly what the climb would have recorded.
+//   ratio:   every lane keeps the best residual of the elements it met (side 1: lowest index among
+//            ties, side 2: highest -- the climb's `<` / `<=`); two team-wide atomic minima + one tie
+//            pass combine them.
+#define MCF_SCAN_K 16
+// `hits` holds the first `hits_cap` entries of the hit list (LDS on the device), the scratch behind v.seg the rest.
+MCF_HD void mcf_pivot_scan(const McfView& v, McfCycle* cy, McfScanAcc* acc, int32_t* hits, int32_t hits_cap,
+                           int32_t lane, int32_t nlanes) {
     McfCtx* c = v.ctx;
     const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
     const int32_t* ord = c->cur ? v.order[1] : v.order[0];
     const int32_t* psz = c->cur ? v.psz[1] : v.psz[0];
+    int32_t* spill = reinterpret_cast<int32_t*>(v.seg);  // scratch the finish pass only fills later; <= n_nodes entries
     if (lane == 0) {
         acc->r1 = INT64_MAX; acc->r2 = INT64_MAX;
         acc->i1 = INT32_MAX; acc->i2 = -1;
-        acc->jpos = -1; acc->rounds = 0;
+        acc->jpos[0] = -1; acc->jpos[1] = -1;
+        acc->nhits = 0;
     }
     const int32_t u = cy->u, w = cy->w;
     const int32_t pu = pcur[u], pw = pcur[w], du = cy->ru.depth, dw = cy->rw.depth;
     const int32_t base1 = cy->n1, base2 = cy->n2;
     MCF_TEAM_BARRIER();
-    int64_t b1r = INT64_MAX, b2r = INT64_MAX;
-    int32_t b1i = -1, b2i = -1;
     int32_t top = (pu > pw ? pu : pw) + 1;  // exclusive
-    bool failed = false;
+    int32_t par = 0, rounds = 0, jpos = -1;
     for (;;) {
         const int32_t lo = top - nlanes * MCF_SCAN_K;
         int32_t sz[MCF_SCAN_K];
@@ -427,36 +439,51 @@ MCF_HD void mcf_pivot_scan(const McfView& v, McfCycle* cy, McfScanAcc* acc, int3
             if (i < 0) continue;
             const bool au = i <= pu && pu - i < sz[k];
             const bool aw = i <= pw && pw - i < sz[k];
-            if (!au && !aw) continue;
-            if (au && aw) { MCF_ATOMIC_MAX32(&acc->jpos, i); continue; }
-            const int32_t nd = ord[i];
-            const McfNode rec = v.node[nd];
-            const McfArcW a = v.arcw[rec.pred >> 1];
-            if (au) {
-                const int32_t idx = base1 + du - rec.depth;
-                v.path1[idx] = nd;
-                v.rec1[idx] = rec;
-                const int64_t r = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
-                if (r < b1r || (r == b1r && idx < b1i)) { b1r = r; b1i = idx; }
-            } else {
-                const int32_t idx = base2 + dw - rec.depth;
-                v.path2[idx] = nd;
-                v.rec2[idx] = rec;
-                const int64_t r = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
-                if (r < b2r || (r == b2r && idx > b2i)) { b2r = r; b2i = idx; }
+            if (au && aw) MCF_ATOMIC_MAX32(&acc->jpos[par], i);
+            else if (au || aw) {
+                const int32_t slot = MCF_ATOMIC_ADD32(&acc->nhits, 1);
+                const int32_t hrec = (i << 1) | (aw ? 1 : 0);
+                if (slot < hits_cap) hits[slot] = hrec; else spill[slot - hits_cap] = hrec;
             }
         }
         MCF_TEAM_BARRIER();
-        const bool found = acc->jpos >= 0;
-        if (lane == 0) acc->rounds += 1;
-        MCF_TEAM_BARRIER();  // nobody may start the next chunk's atomics before everybody has read jpos
-        if (found) break;
-        if (lo <= 0) { failed = true; break; }  // position 0 is the root, a common ancestor: cannot happen
+        // the next round's atomics go to the other slot: nobody can overtake a lane still reading this one
+        jpos = acc->jpos[par];
+        par ^= 1;
+        ++rounds;
+        if (jpos >= 0 || lo <= 0) break;
         top = lo;
     }
-    if (failed) {
+    if (jpos < 0) {  // position 0 is the root, a common ancestor: cannot happen
         if (lane == 0) c->status = MCF_INTERNAL_ERROR;
         return;
+    }
+    int64_t b1r = INT64_MAX, b2r = INT64_MAX;
+    int32_t b1i = -1, b2i = -1;
+    const int32_t nhits = acc->nhits;  // final: every append precedes the last barrier
+    if (lane == nlanes - 1) {  // the join's record rides along with the hit pass (this lane is the last to get a hit)
+        const int32_t jn = ord[jpos];
+        acc->jnode = jn;
+        acc->join = v.node[jn];
+    }
+    for (int32_t t = lane; t < nhits; t += nlanes) {
+        const int32_t hrec = t < hits_cap ? hits[t] : spill[t - hits_cap];
+        const int32_t nd = ord[hrec >> 1];
+        const McfNode rec = v.node[nd];
+        const McfArcW a = v.arcw[rec.pred >> 1];
+        if (!(hrec & 1)) {
+            const int32_t idx = base1 + du - rec.depth;
+            v.path1[idx] = nd;
+            v.rec1[idx] = rec;
+            const int64_t r = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
+            if (r < b1r || (r == b1r && idx < b1i)) { b1r = r; b1i = idx; }
+        } else {
+            const int32_t idx = base2 + dw - rec.depth;
+            v.path2[idx] = nd;
+            v.rec2[idx] = rec;
+            const int64_t r = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
+            if (r < b2r || (r == b2r && idx > b2i)) { b2r = r; b2i = idx; }
+        }
     }
     if (b1i >= 0) MCF_ATOMIC_MIN64(&acc->r1, b1r);
     if (b2i >= 0) MCF_ATOMIC_MIN64(&acc->r2, b2r);
@@ -468,14 +495,14 @@ MCF_HD void mcf_pivot_scan(const McfView& v, McfCycle* cy, McfScanAcc* acc, int3
         // merge with what the climb found: its elements have the lower path indices
         if (acc->i1 != INT32_MAX && acc->r1 < cy->d1) { cy->d1 = acc->r1; cy->k1 = acc->i1; }
         if (acc->i2 >= 0 && acc->r2 <= cy->d2) { cy->d2 = acc->r2; cy->k2 = acc->i2; }
-        const int32_t jn = ord[acc->jpos];
-        const McfNode rj = v.node[jn];
+        const int32_t jn = acc->jnode;
+        const McfNode rj = acc->join;
         cy->n1 = base1 + du - rj.depth;
         cy->n2 = base2 + dw - rj.depth;
         cy->u = jn; cy->w = jn;
         cy->ru = rj; cy->rw = rj;
         c->scans += 1;
-        c->scan_rounds += acc->rounds;
+        c->scan_rounds += rounds;
     }
 }
 
@@ -566,7 +593,7 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     if (!mcf_pivot_climb(v, &cy, v.psz[0] ? v.ctx->climb_budget : INT32_MAX)) return;
     if (cy.u != cy.w) {
         McfScanAcc acc;
-        mcf_pivot_scan(v, &cy, &acc, 0, 1);
+        mcf_pivot_scan(v, &cy, &acc, nullptr, 0, 0, 1);
         if (v.ctx->status != MCF_RUNNING) return;
     }
     mcf_pivot_decide(v, cy);

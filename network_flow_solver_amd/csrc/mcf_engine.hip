@@ -321,27 +321,43 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce(const McfCand* __rest
 }
 
 // ------------------------------------------------------------------ k_pivot
-__global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView v, const McfCand* __restrict__ cand, int ncand,
+// One workgroup; latency-bound, so the point is to keep the chain of dependent global round trips short:
+// the control block is staged in LDS for the whole kernel (begin / decide / finish read and write dozens
+// of its fields), the candidate loads are in flight while it arrives, the cycle comes from the
+// position-space scan (~4 dependent round trips whatever its length) with the hit list in LDS.
+constexpr int kHitsLds = 4096;  // hit-list entries kept in LDS (a longer cycle spills to global scratch)
+
+__global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCand* __restrict__ cand, int ncand,
                                                           int32_t rule, int have_sweep) {
+    __shared__ McfCtx s_ctx;
+    __shared__ McfCycle s_cy;
+    __shared__ McfScanAcc s_acc;
+    __shared__ int s_go;  // 0 = nothing to pivot on, 1 = the climb reached the join, 2 = the scan has to finish the cycle
+    __shared__ int32_t s_hits[kHitsLds];
+    constexpr int kCtxWords = (int)(sizeof(McfCtx) / 4);
+    static_assert(sizeof(McfCtx) % 4 == 0 && kCtxWords <= kPivotThreads, "control block staging");
+    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&s_ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
+    McfCand first = McfCand{0, -1};
+    if ((int)threadIdx.x < ncand) first = cand[threadIdx.x];  // in flight together with the control block
+    __syncthreads();
+    McfView v = g;
+    v.ctx = &s_ctx;
     // candidate-list rule: slots without a pricing launch in front (have_sweep == 0) can only run
     // minor iterations; once the list is exhausted they idle until the next slot that sweeps
-    if (v.ctx->status != MCF_RUNNING || (!have_sweep && v.ctx->minor_left <= 0)) {
-        if (threadIdx.x == 0) v.ctx->apply = 0;
+    if (s_ctx.status != MCF_RUNNING || (!have_sweep && s_ctx.minor_left <= 0)) {
+        if (threadIdx.x == 0) g.ctx->apply = 0;
         return;
     }
     int64_t key = 0, arc = -1;
     // candidate-list rule, minor iteration: no sweep ran; the listed arcs are re-priced here
     // against the current state (resident reduced cost or potentials)
-    const bool minor = rule == MCF_RULE_CANDIDATE_LIST && v.ctx->minor_left > 0;
+    const bool minor = rule == MCF_RULE_CANDIDATE_LIST && s_ctx.minor_left > 0;
     for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
-        const McfCand cd = cand[i];
+        const McfCand cd = i == (int)threadIdx.x ? first : cand[i];
         const int64_t kk = minor ? mcf_minor_key(v, cd.arc) : cd.key;
         if (mcf_cand_better(kk, cd.arc, key, arc)) { key = kk; arc = cd.arc; }
     }
     block_argmax<kPivotThreads>(key, arc);
-    __shared__ McfCycle s_cy;
-    __shared__ McfScanAcc s_acc;
-    __shared__ int s_go;  // 0 = nothing to pivot on, 1 = the climb reached the join, 2 = the scan has to finish the cycle
     if (threadIdx.x == 0) {
         McfCtx* c = v.ctx;
         if (c->pivots < c->max_pivots) {
@@ -367,10 +383,12 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView v, const McfCan
     }
     __syncthreads();
     const int go = s_go;
-    if (go == 2) mcf_pivot_scan(v, &s_cy, &s_acc, threadIdx.x, kPivotThreads);  // the whole workgroup, barriers inside
-    if (go && threadIdx.x == 0 && v.ctx->status == MCF_RUNNING) mcf_pivot_decide(v, s_cy);
+    if (go == 2) mcf_pivot_scan(v, &s_cy, &s_acc, s_hits, kHitsLds, threadIdx.x, kPivotThreads);  // barriers inside
+    if (go && threadIdx.x == 0 && s_ctx.status == MCF_RUNNING) mcf_pivot_decide(v, s_cy);
     __syncthreads();
     mcf_pivot_finish(v, threadIdx.x, kPivotThreads);  // array updates, one path element per lane
+    // publish the control block for the apply / pricing launches that follow (finish only reads it)
+    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&s_ctx)[threadIdx.x];
 }
 
 // ------------------------------------------------------------------ k_apply
@@ -567,7 +585,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         }
         __syncthreads();
         const int go = s_go;
-        if (go == 2) mcf_pivot_scan(v, &s_cy, &s_acc, threadIdx.x, kSmallThreads);
+        if (go == 2) mcf_pivot_scan(v, &s_cy, &s_acc, reinterpret_cast<int32_t*>(v.seg), INT32_MAX, threadIdx.x, kSmallThreads);
         if (go && threadIdx.x == 0 && c->status == MCF_RUNNING) mcf_pivot_decide(v, s_cy);
         STAMP(3);
         __syncthreads();
@@ -987,12 +1005,12 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         }
     }
     // cycle search: how many round trips the one-lane climb takes before the workgroup-wide scan over
-    // preorder positions finishes the cycle (auto: the LDS loop scans at once -- a barrier costs less
-    // than a dependent LDS round trip there; the global path climbs a few steps first because most
-    // netgen cycles close within them)
+    // preorder positions finishes the cycle.  Auto = none: measured on MI355X (profiles/r01_f_*), scanning
+    // at once beats every hybrid from 256 to 65 536 nodes -- a dependent global round trip per tree level
+    // costs more than the whole scan's ~4 -- by 1.1x (netgen_8_08a) to 4.5x (goto_8_16a, cycles of ~450 arcs).
     if (!scan_ok) h->climb_budget = INT32_MAX;
     else if (opt.cycle_scan > 0) h->climb_budget = opt.cycle_scan - 1;
-    else h->climb_budget = h->small ? 0 : 8;
+    else h->climb_budget = 0;
     // resident reduced costs for everything that does not take the fused LDS path
     h->rcached = !h->small && !opt.no_rcache && im.m > 0;
     if (h->rcached) {
