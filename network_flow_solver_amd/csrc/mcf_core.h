@@ -70,6 +70,22 @@ enum McfStatus : int32_t {
 #define MCF_RULE_CANDIDATE_LIST 2
 #endif
 
+// Diagnostic build (-DMCF_STAMPS): cycle stamps of the one-workgroup pivot kernel, accumulated per phase.
+#if defined(MCF_STAMPS) && defined(__HIPCC__)
+__shared__ unsigned long long mcf_stamp_acc[24];
+__shared__ unsigned long long mcf_stamp_last;
+#define MCF_PSTAMP(slot)                                                     \
+    do {                                                                      \
+        if (threadIdx.x == 0) {                                               \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+            mcf_stamp_acc[slot] += now_ - mcf_stamp_last;                     \
+            mcf_stamp_last = now_;                                            \
+        }                                                                     \
+    } while (0)
+#else
+#define MCF_PSTAMP(slot) do {} while (0)
+#endif
+
 // One 16-byte record per node: a cycle walk needs exactly one load per step.
 struct alignas(16) McfNode {
     int32_t parent;  // parent node (root: -1)
@@ -149,6 +165,7 @@ struct McfCtx {
     int32_t pv_vin_depth;      // depth of the new parent v_in
     int32_t pv_first, pv_second;  // end points of the entering arc in push order
     int64_t pv_rc;             // its exact reduced cost
+    int64_t pv_cap;            // its capacity
     int64_t pv_delta;
     // ---- cycle search: round trips the pointer-chasing climb may take before the position-space scan
     // takes over (only when the view carries psz[]); diagnostics
@@ -178,6 +195,8 @@ struct McfView {
     int32_t* path2;         // [n_nodes] scratch: nodes on the `second` side
     McfNode* rec1;          // [n_nodes] scratch: their node records as read during the walk
     McfNode* rec2;          // [n_nodes]
+    int32_t* ppos1;         // [n_nodes] scratch: their preorder positions (old view), so that the finish pass
+    int32_t* ppos2;         // [n_nodes]   needs no dependent position look-ups
     McfSeg* seg;            // [2*n_nodes + 2] scratch
     McfCtx* ctx;
     // ---- resident reduced costs (large instances; nullptr = price by gathering potentials)
@@ -247,13 +266,25 @@ MCF_HD int64_t mcf_minor_key(const McfView& v, int64_t packed_arc) {
 //         bookkeeping, stem re-parenting, the segments of the block permutation.  Each path
 //         element has a closed form from the recorded records, so lanes just stride over them.
 // ---------------------------------------------------------------------------
+// Where a cycle is recorded: node ids, their records as read, their preorder positions, per side.
+struct McfPaths {
+    int32_t *path1, *path2;
+    McfNode *rec1, *rec2;
+    int32_t *ppos1, *ppos2;
+};
+MCF_HD McfPaths mcf_view_paths(const McfView& v) { return McfPaths{v.path1, v.path2, v.rec1, v.rec2, v.ppos1, v.ppos2}; }
+
 // State of the cycle search, shared by the climb (one lane) and the scan (the whole team).
 struct McfCycle {
     int64_t d1, d2;        // smallest residual so far on the first / second side (MCF_INF: none)
     int32_t k1, k2;        // index of that blocking node in path1 / path2 (-1: none)
     int32_t n1, n2;        // path elements recorded so far
     int32_t u, w;          // where the two climbs stand; u == w: that node is the join
+    int32_t pu, pw;        // their preorder positions
     McfNode ru, rw;        // their records
+    int32_t p0u, p0w;      // positions and records of the entering arc's end points (first / second)
+    McfNode r0u, r0w;
+    int32_t small;         // the scan recorded the cycle in the small (LDS) path buffers, not in v.path*/rec*/ppos*
 };
 
 // Accumulators of the team-wide scan (LDS on the device).
@@ -320,6 +351,7 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
     const int64_t rc = v.rcache ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
 
     c->pv_e = e; c->pv_s = s; c->pv_first = first; c->pv_second = second; c->pv_rc = rc;
+    c->pv_cap = v.arcw[e].cap;
     return true;
 }
 
@@ -333,8 +365,14 @@ MCF_HD void mcf_cycle_init(const McfView& v, McfCycle* cy) {
     const McfCtx* c = v.ctx;
     cy->u = c->pv_first;
     cy->w = c->pv_second;
+    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
     cy->ru = v.node[cy->u];
     cy->rw = v.node[cy->w];
+    cy->pu = pcur[cy->u];
+    cy->pw = pcur[cy->w];
+    cy->r0u = cy->ru; cy->r0w = cy->rw;
+    cy->p0u = cy->pu; cy->p0w = cy->pw;
+    cy->small = 0;
     cy->d1 = MCF_INF; cy->d2 = MCF_INF;
     cy->k1 = -1; cy->k2 = -1;
     cy->n1 = 0; cy->n2 = 0;
@@ -346,7 +384,8 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, McfCycle* cy, int32_t budget) {
     // Depth-balanced climb: per round trip every side that is at least as deep as the other moves
     // up one arc (both when they are level), so the walk costs max(d1, d2) dependent loads instead of
     // d1 + d2; both parents' records and both arcs are requested before anything is looked at.
-    int32_t u = cy->u, w = cy->w;
+    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
+    int32_t u = cy->u, w = cy->w, pu = cy->pu, pw = cy->pw;
     McfNode ru = cy->ru, rw = cy->rw;
     int64_t d1 = cy->d1, d2 = cy->d2;
     int32_t k1 = cy->k1, k2 = cy->k2, n1 = cy->n1, n2 = cy->n2;
@@ -354,31 +393,36 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, McfCycle* cy, int32_t budget) {
     while (u != w && trips < budget) {
         const bool step_u = ru.depth >= rw.depth, step_w = rw.depth >= ru.depth;
         McfNode nu = ru, nw = rw;
+        int32_t npu = pu, npw = pw;
         McfArcW au = McfArcW{0, 0}, aw = McfArcW{0, 0};
-        if (step_u) { nu = v.node[ru.parent]; au = v.arcw[ru.pred >> 1]; }
-        if (step_w) { nw = v.node[rw.parent]; aw = v.arcw[rw.pred >> 1]; }
+        if (step_u) { nu = v.node[ru.parent]; npu = pcur[ru.parent]; au = v.arcw[ru.pred >> 1]; }
+        if (step_w) { nw = v.node[rw.parent]; npw = pcur[rw.parent]; aw = v.arcw[rw.pred >> 1]; }
         if (step_u) {
             // first side is walked against the flow: an up arc loses flow, a down arc gains
             const int64_t r = (ru.pred & 1) ? au.flow : (au.cap >= MCF_INF ? MCF_INF : au.cap - au.flow);
             if (r < d1) { d1 = r; k1 = n1; }
             v.path1[n1] = u;
             v.rec1[n1] = ru;
+            v.ppos1[n1] = pu;
             ++n1;
             u = ru.parent;
             ru = nu;
+            pu = npu;
         }
         if (step_w) {
             const int64_t r = (rw.pred & 1) ? (aw.cap >= MCF_INF ? MCF_INF : aw.cap - aw.flow) : aw.flow;
             if (r <= d2) { d2 = r; k2 = n2; }
             v.path2[n2] = w;
             v.rec2[n2] = rw;
+            v.ppos2[n2] = pw;
             ++n2;
             w = rw.parent;
             rw = nw;
+            pw = npw;
         }
         if (++trips > v.n_nodes) { c->status = MCF_INTERNAL_ERROR; return false; }  // depths out of sync: never spin
     }
-    cy->u = u; cy->w = w; cy->ru = ru; cy->rw = rw;
+    cy->u = u; cy->w = w; cy->ru = ru; cy->rw = rw; cy->pu = pu; cy->pw = pw;
     cy->d1 = d1; cy->d2 = d2; cy->k1 = k1; cy->k2 = k2; cy->n1 = n1; cy->n2 = n2;
     return true;
 }
@@ -401,11 +445,45 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, McfCycle* cy, int32_t budget) {
 //            ties, side 2: highest -- the climb's `<` / `<=`); two team-wide atomic minima + one tie
 //            pass combine them.
 #define MCF_SCAN_K 16
+struct McfScanBest { int64_t b1r, b2r; int32_t b1i, b2i; };
+
+// The dense pass over the hit list: node id, record, tree arc of every one-sided ancestor -> its slot in
+// the path buffers `pb`, and this lane's best residual per side.
+MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_t* ord, const int32_t* hits,
+                              int32_t hits_cap, const int32_t* spill, int32_t nhits, int32_t base1, int32_t base2,
+                              int32_t du, int32_t dw, int32_t lane, int32_t nlanes, McfScanBest* out) {
+    int64_t b1r = INT64_MAX, b2r = INT64_MAX;
+    int32_t b1i = -1, b2i = -1;
+    for (int32_t t = lane; t < nhits; t += nlanes) {
+        const int32_t hrec = t < hits_cap ? hits[t] : spill[t - hits_cap];
+        const int32_t nd = ord[hrec >> 1];
+        const McfNode rec = v.node[nd];
+        const McfArcW a = v.arcw[rec.pred >> 1];
+        if (!(hrec & 1)) {
+            const int32_t idx = base1 + du - rec.depth;
+            pb.path1[idx] = nd;
+            pb.rec1[idx] = rec;
+            pb.ppos1[idx] = hrec >> 1;
+            const int64_t r = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
+            if (r < b1r || (r == b1r && idx < b1i)) { b1r = r; b1i = idx; }
+        } else {
+            const int32_t idx = base2 + dw - rec.depth;
+            pb.path2[idx] = nd;
+            pb.rec2[idx] = rec;
+            pb.ppos2[idx] = hrec >> 1;
+            const int64_t r = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
+            if (r < b2r || (r == b2r && idx > b2i)) { b2r = r; b2i = idx; }
+        }
+    }
+    out->b1r = b1r; out->b2r = b2r; out->b1i = b1i; out->b2i = b2i;
+}
 // `hits` holds the first `hits_cap` entries of the hit list (LDS on the device), the scratch behind v.seg the rest.
-MCF_HD void mcf_pivot_scan(const McfView& v, McfCycle* cy, McfScanAcc* acc, int32_t* hits, int32_t hits_cap,
-                           int32_t lane, int32_t nlanes) {
+// `sp`: small buffers of `small_cap` entries each (LDS on the device; cap 0 = none); a cycle found by the
+// scan alone that fits is recorded there (cy->small = 1), which spares the decide / finish passes a
+// global round trip per look-up.
+MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_cap, McfCycle* cy, McfScanAcc* acc,
+                           int32_t* hits, int32_t hits_cap, int32_t lane, int32_t nlanes) {
     McfCtx* c = v.ctx;
-    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
     const int32_t* ord = c->cur ? v.order[1] : v.order[0];
     const int32_t* psz = c->cur ? v.psz[1] : v.psz[0];
     int32_t* spill = reinterpret_cast<int32_t*>(v.seg);  // scratch the finish pass only fills later; <= n_nodes entries
@@ -415,10 +493,10 @@ MCF_HD void mcf_pivot_scan(const McfView& v, McfCycle* cy, McfScanAcc* acc, int3
         acc->jpos[0] = -1; acc->jpos[1] = -1;
         acc->nhits = 0;
     }
-    const int32_t u = cy->u, w = cy->w;
-    const int32_t pu = pcur[u], pw = pcur[w], du = cy->ru.depth, dw = cy->rw.depth;
+    const int32_t pu = cy->pu, pw = cy->pw, du = cy->ru.depth, dw = cy->rw.depth;
     const int32_t base1 = cy->n1, base2 = cy->n2;
     MCF_TEAM_BARRIER();
+    MCF_PSTAMP(4);
     int32_t top = (pu > pw ? pu : pw) + 1;  // exclusive
     int32_t par = 0, rounds = 0, jpos = -1;
     for (;;) {
@@ -458,33 +536,22 @@ MCF_HD void mcf_pivot_scan(const McfView& v, McfCycle* cy, McfScanAcc* acc, int3
         if (lane == 0) c->status = MCF_INTERNAL_ERROR;
         return;
     }
-    int64_t b1r = INT64_MAX, b2r = INT64_MAX;
-    int32_t b1i = -1, b2i = -1;
+    MCF_PSTAMP(5);
     const int32_t nhits = acc->nhits;  // final: every append precedes the last barrier
     if (lane == nlanes - 1) {  // the join's record rides along with the hit pass (this lane is the last to get a hit)
         const int32_t jn = ord[jpos];
         acc->jnode = jn;
         acc->join = v.node[jn];
     }
-    for (int32_t t = lane; t < nhits; t += nlanes) {
-        const int32_t hrec = t < hits_cap ? hits[t] : spill[t - hits_cap];
-        const int32_t nd = ord[hrec >> 1];
-        const McfNode rec = v.node[nd];
-        const McfArcW a = v.arcw[rec.pred >> 1];
-        if (!(hrec & 1)) {
-            const int32_t idx = base1 + du - rec.depth;
-            v.path1[idx] = nd;
-            v.rec1[idx] = rec;
-            const int64_t r = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
-            if (r < b1r || (r == b1r && idx < b1i)) { b1r = r; b1i = idx; }
-        } else {
-            const int32_t idx = base2 + dw - rec.depth;
-            v.path2[idx] = nd;
-            v.rec2[idx] = rec;
-            const int64_t r = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
-            if (r < b2r || (r == b2r && idx > b2i)) { b2r = r; b2i = idx; }
-        }
-    }
+    // every path index is < base + nhits: with nothing climbed and few hits the small buffers hold the cycle.
+    // Two calls rather than selected pointers: each inlined copy then has one known address space.
+    const bool small = base1 == 0 && base2 == 0 && nhits <= small_cap;
+    McfScanBest best;
+    if (small) mcf_scan_hit_pass(v, sp, ord, hits, hits_cap, spill, nhits, base1, base2, du, dw, lane, nlanes, &best);
+    else mcf_scan_hit_pass(v, mcf_view_paths(v), ord, hits, hits_cap, spill, nhits, base1, base2, du, dw, lane, nlanes, &best);
+    const int64_t b1r = best.b1r, b2r = best.b2r;
+    const int32_t b1i = best.b1i, b2i = best.b2i;
+    MCF_PSTAMP(6);
     if (b1i >= 0) MCF_ATOMIC_MIN64(&acc->r1, b1r);
     if (b2i >= 0) MCF_ATOMIC_MIN64(&acc->r2, b2r);
     MCF_TEAM_BARRIER();
@@ -501,20 +568,22 @@ MCF_HD void mcf_pivot_scan(const McfView& v, McfCycle* cy, McfScanAcc* acc, int3
         cy->n2 = base2 + dw - rj.depth;
         cy->u = jn; cy->w = jn;
         cy->ru = rj; cy->rw = rj;
+        cy->small = small ? 1 : 0;
         c->scans += 1;
         c->scan_rounds += rounds;
     }
+    MCF_PSTAMP(7);
 }
 
 // Step 3 (one lane): ratio-test decision + everything the finish / apply passes need to know.
-MCF_HD void mcf_pivot_decide(const McfView& v, const McfCycle& cy) {
+MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycle& cy) {
     McfCtx* c = v.ctx;
     const int32_t e = c->pv_e, s = c->pv_s, first = c->pv_first, second = c->pv_second;
     const int64_t rc = c->pv_rc;
     const int64_t d1 = cy.d1, d2 = cy.d2;
     const int32_t k1 = cy.k1, k2 = cy.k2, n1 = cy.n1, n2 = cy.n2;
     const McfNode ru = cy.ru;  // joined: ru == rw == the join's record
-    const int64_t de = v.arcw[e].cap;  // residual of the entering arc in its push direction
+    const int64_t de = c->pv_cap;  // residual of the entering arc in its push direction (a non-basic arc sits at a bound)
     int32_t result;
     int64_t delta;
     if (d2 <= de && d2 <= d1) { result = 2; delta = d2; }
@@ -543,7 +612,7 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfCycle& cy) {
 
     // --- basis swap (simplex.py:1335-1425): scalar decisions only
     const int32_t k = result == 1 ? k1 : k2;                 // stem[0] = u_in ... stem[k] = q
-    const McfNode* srec = result == 1 ? v.rec1 : v.rec2;
+    const McfNode* srec = result == 1 ? pp.rec1 : pp.rec2;
     const int32_t v_in = result == 1 ? second : first;
     const McfNode rq = srec[k];
     const bool tail_in_t2 = (result == 1) == (s > 0);
@@ -556,13 +625,10 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfCycle& cy) {
     c->pv_tail_in_t2 = tail_in_t2 ? 1 : 0;
     c->sigma = tail_in_t2 ? -rc : rc;  // potential shift that zeroes the entering arc's reduced cost
 
-    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
-    const int32_t q = (result == 1 ? v.path1 : v.path2)[k];
-    const int32_t S = rq.size, a0 = pcur[q];
-    // v_in's record: the first element of the other side, or the join itself when that side is empty
-    const int32_t nother = result == 1 ? n2 : n1;
-    const McfNode rvin = nother > 0 ? (result == 1 ? v.rec2[0] : v.rec1[0]) : ru;  // ru == rw == join record
-    const int32_t pvin = pcur[v_in];
+    const int32_t S = rq.size, a0 = (result == 1 ? pp.ppos1 : pp.ppos2)[k];
+    // v_in is the entering arc's end point on the other side: its record and position were read at the start
+    const McfNode rvin = result == 1 ? cy.r0w : cy.r0u;
+    const int32_t pvin = result == 1 ? cy.p0w : cy.p0u;
     c->pv_vin_depth = rvin.depth;
     // insertion point in OLD coordinates: directly behind v_in, or at the end of
     // v_in's block -- whichever moves fewer array elements
@@ -593,13 +659,13 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     if (!mcf_pivot_climb(v, &cy, v.psz[0] ? v.ctx->climb_budget : INT32_MAX)) return;
     if (cy.u != cy.w) {
         McfScanAcc acc;
-        mcf_pivot_scan(v, &cy, &acc, nullptr, 0, 0, 1);
+        mcf_pivot_scan(v, mcf_view_paths(v), 0, &cy, &acc, nullptr, 0, 0, 1);
         if (v.ctx->status != MCF_RUNNING) return;
     }
-    mcf_pivot_decide(v, cy);
+    mcf_pivot_decide(v, mcf_view_paths(v), cy);
 }
 
-MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
+MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane, int32_t nlanes) {
     const McfCtx* c = v.ctx;
     const int32_t stage = c->stage;
     if (stage == 0) return;
@@ -610,7 +676,7 @@ MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
     if (delta > 0) {
         for (int32_t i = lane; i < n1 + n2; i += nlanes) {
             const bool side1 = i < n1;
-            const int32_t p = side1 ? v.rec1[i].pred : v.rec2[i - n1].pred;
+            const int32_t p = side1 ? pp.rec1[i].pred : pp.rec2[i - n1].pred;
             const bool up = (p & 1) != 0;
             // first side is walked against the flow, second side with it
             v.arcw[p >> 1].flow += (side1 == up) ? -delta : delta;
@@ -623,11 +689,11 @@ MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
     }
 
     const int32_t result = c->pv_result, k = c->pv_k, v_in = c->pv_vin;
-    const int32_t* stem = result == 1 ? v.path1 : v.path2;
-    const McfNode* srec = result == 1 ? v.rec1 : v.rec2;
+    const int32_t* stem = result == 1 ? pp.path1 : pp.path2;
+    const McfNode* srec = result == 1 ? pp.rec1 : pp.rec2;
     const int32_t nstem_side = result == 1 ? n1 : n2;
-    const int32_t* other = result == 1 ? v.path2 : v.path1;
-    const McfNode* orec = result == 1 ? v.rec2 : v.rec1;
+    const int32_t* other = result == 1 ? pp.path2 : pp.path1;
+    const McfNode* orec = result == 1 ? pp.rec2 : pp.rec1;
     const int32_t nother = result == 1 ? n2 : n1;
     const int32_t S = c->t2_size, b = c->t2_new;
     if (lane == 0) {
@@ -639,25 +705,25 @@ MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
     // The position-space copies are written at the OLD position into BOTH buffers: a node outside the
     // affected range keeps its position (both buffers must agree there), one inside is moved -- together
     // with this value -- by the apply pass, which reads psz[cur] and overwrites psz[cur ^ 1].
-    const int32_t* pcur0 = c->cur ? v.posbuf[1] : v.posbuf[0];
+    const int32_t* spos = result == 1 ? pp.ppos1 : pp.ppos2;
+    const int32_t* opos = result == 1 ? pp.ppos2 : pp.ppos1;
     for (int32_t i = k + 1 + lane; i < nstem_side; i += nlanes) {
         v.node[stem[i]].size = srec[i].size - S;
-        if (v.psz[0]) { const int32_t p = pcur0[stem[i]]; v.psz[0][p] = srec[i].size - S; v.psz[1][p] = srec[i].size - S; }
+        if (v.psz[0]) { const int32_t p = spos[i]; v.psz[0][p] = srec[i].size - S; v.psz[1][p] = srec[i].size - S; }
     }
     for (int32_t i = lane; i < nother; i += nlanes) {
         v.node[other[i]].size = orec[i].size + S;
-        if (v.psz[0]) { const int32_t p = pcur0[other[i]]; v.psz[0][p] = orec[i].size + S; v.psz[1][p] = orec[i].size + S; }
+        if (v.psz[0]) { const int32_t p = opos[i]; v.psz[0][p] = orec[i].size + S; v.psz[1][p] = orec[i].size + S; }
     }
 
     // re-root T2 at u_in: reverse the stem and emit the block permutation.
     // Old layout: block(s_i) = [p_i, p_i + z_i), nested, s_k = q.  New layout: block(s_0), then
     // for i = 1..k: s_i + what precedes block(s_{i-1}) inside block(s_i), then what follows it;
     // piece i starts at b + z_{i-1} because pieces 0..i-1 are exactly old block(s_{i-1}).
-    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
     const int32_t base_depth = c->pv_vin_depth + 1;
     for (int32_t i = lane; i <= k; i += nlanes) {
         const McfNode r = srec[i];
-        const int32_t p = pcur[stem[i]];
+        const int32_t p = spos[i];
         const int32_t dd = base_depth + i - r.depth;  // piece i moves from depth(s_i) to depth(v_in) + 1 + i
         McfNode nr;
         nr.depth = r.depth;  // the apply pass adds dd to every node of the piece, s_i included
@@ -668,7 +734,7 @@ MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
             v.seg[0] = McfSeg{b, p, r.size, dd};
         } else {
             const McfNode rp = srec[i - 1];
-            const int32_t pp = pcur[stem[i - 1]];
+            const int32_t pp = spos[i - 1];
             nr.parent = stem[i - 1];
             nr.pred = rp.pred ^ 1;  // the arc s_{i-1} used to hang on now carries s_i: direction bit flips
             nr.size = S - rp.size;  // all of T2 except what stays below s_{i-1}
@@ -686,7 +752,7 @@ MCF_HD void mcf_pivot_finish(const McfView& v, int32_t lane, int32_t nlanes) {
 // Convenience for single-threaded callers (CPU emulation): the whole pivot.
 MCF_HD void mcf_pivot_seq(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
     mcf_pivot_walk(v, best_key, best_arc, rule);
-    mcf_pivot_finish(v, 0, 1);
+    mcf_pivot_finish(v, mcf_view_paths(v), 0, 1);
 }
 
 // ---------------------------------------------------------------------------

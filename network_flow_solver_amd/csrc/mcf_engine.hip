@@ -325,7 +325,11 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce(const McfCand* __rest
 // the control block is staged in LDS for the whole kernel (begin / decide / finish read and write dozens
 // of its fields), the candidate loads are in flight while it arrives, the cycle comes from the
 // position-space scan (~4 dependent round trips whatever its length) with the hit list in LDS.
-constexpr int kHitsLds = 4096;  // hit-list entries kept in LDS (a longer cycle spills to global scratch)
+#ifdef MCF_STAMPS
+__device__ unsigned long long g_pivot_stamps[24];
+#endif
+constexpr int kHitsLds = 4096;   // hit-list entries kept in LDS (a longer cycle spills to global scratch)
+constexpr int kSmallPath = 512;  // cycles up to this many nodes are recorded in LDS instead of the global path scratch
 
 __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCand* __restrict__ cand, int ncand,
                                                           int32_t rule, int have_sweep) {
@@ -334,14 +338,20 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     __shared__ McfScanAcc s_acc;
     __shared__ int s_go;  // 0 = nothing to pivot on, 1 = the climb reached the join, 2 = the scan has to finish the cycle
     __shared__ int32_t s_hits[kHitsLds];
+    __shared__ int32_t s_path[2][kSmallPath], s_ppos[2][kSmallPath];
+    __shared__ McfNode s_rec[2][kSmallPath];
     constexpr int kCtxWords = (int)(sizeof(McfCtx) / 4);
     static_assert(sizeof(McfCtx) % 4 == 0 && kCtxWords <= kPivotThreads, "control block staging");
+#ifdef MCF_STAMPS
+    if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = __builtin_amdgcn_s_memtime(); }
+#endif
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&s_ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
     McfCand first = McfCand{0, -1};
     if ((int)threadIdx.x < ncand) first = cand[threadIdx.x];  // in flight together with the control block
     __syncthreads();
     McfView v = g;
     v.ctx = &s_ctx;
+    MCF_PSTAMP(0);
     // candidate-list rule: slots without a pricing launch in front (have_sweep == 0) can only run
     // minor iterations; once the list is exhausted they idle until the next slot that sweeps
     if (s_ctx.status != MCF_RUNNING || (!have_sweep && s_ctx.minor_left <= 0)) {
@@ -357,7 +367,12 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
         const int64_t kk = minor ? mcf_minor_key(v, cd.arc) : cd.key;
         if (mcf_cand_better(kk, cd.arc, key, arc)) { key = kk; arc = cd.arc; }
     }
-    block_argmax<kPivotThreads>(key, arc);
+    if (ncand <= 64) {  // one wave holds every candidate: no cross-wave stage
+        if (threadIdx.x < 64) wave_argmax(key, arc);
+    } else {
+        block_argmax<kPivotThreads>(key, arc);
+    }
+    MCF_PSTAMP(1);
     if (threadIdx.x == 0) {
         McfCtx* c = v.ctx;
         if (c->pivots < c->max_pivots) {
@@ -375,6 +390,7 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
         }
         int go = 0;
         if (mcf_pivot_begin(v, key, arc, rule)) {
+            MCF_PSTAMP(2);
             mcf_cycle_init(v, &s_cy);
             // sequential part: at most climb_budget dependent round trips
             if (mcf_pivot_climb(v, &s_cy, v.psz[0] ? c->climb_budget : INT32_MAX)) go = s_cy.u == s_cy.w ? 1 : 2;
@@ -382,13 +398,28 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
         s_go = go;
     }
     __syncthreads();
+    MCF_PSTAMP(3);
     const int go = s_go;
-    if (go == 2) mcf_pivot_scan(v, &s_cy, &s_acc, s_hits, kHitsLds, threadIdx.x, kPivotThreads);  // barriers inside
-    if (go && threadIdx.x == 0 && s_ctx.status == MCF_RUNNING) mcf_pivot_decide(v, s_cy);
+    const McfPaths gp = mcf_view_paths(v);                                                    // cycle scratch in global memory
+    const McfPaths sp = McfPaths{s_path[0], s_path[1], s_rec[0], s_rec[1], s_ppos[0], s_ppos[1]};  // ... and in LDS
+    if (go == 2) mcf_pivot_scan(v, sp, kSmallPath, &s_cy, &s_acc, s_hits, kHitsLds, threadIdx.x, kPivotThreads);  // barriers inside
+    // s_cy.small is written by lane 0 at the very end of the scan: lane 0 may use it at once, the others after the barrier.
+    // Separate calls for the two scratch locations: each inlined copy works on one known address space.
+    if (go && threadIdx.x == 0 && s_ctx.status == MCF_RUNNING) {
+        if (s_cy.small) mcf_pivot_decide(v, sp, s_cy); else mcf_pivot_decide(v, gp, s_cy);
+    }
+    MCF_PSTAMP(8);
     __syncthreads();
-    mcf_pivot_finish(v, threadIdx.x, kPivotThreads);  // array updates, one path element per lane
+    if (go && s_cy.small) mcf_pivot_finish(v, sp, threadIdx.x, kPivotThreads);  // array updates, one path element per lane
+    else mcf_pivot_finish(v, gp, threadIdx.x, kPivotThreads);
+    MCF_PSTAMP(9);
     // publish the control block for the apply / pricing launches that follow (finish only reads it)
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&s_ctx)[threadIdx.x];
+#ifdef MCF_STAMPS
+    __syncthreads();
+    MCF_PSTAMP(10);
+    if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i]; g_pivot_stamps[23] += 1; }
+#endif
 }
 
 // ------------------------------------------------------------------ k_apply
@@ -412,7 +443,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
 // mcf_apply_one) and copies the state back.  Same arc sets, same tie rule, same core functions
 // as the three-kernel path, so the pivot sequence is identical.
 struct SmallLayout {
-    uint32_t tail, head, cost, orig, state, weight, arcw, pi, node, order0, order1, pos0, pos1, psz0, psz1, path1, path2, rec1, rec2, seg, ctx, total;
+    uint32_t tail, head, cost, orig, state, weight, arcw, pi, node, order0, order1, pos0, pos1, psz0, psz1, path1, path2, ppos1, ppos2, rec1, rec2, seg, ctx, total;
 };
 
 constexpr int kSmallThreads = 1024;
@@ -462,6 +493,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     v.order[1] = reinterpret_cast<int32_t*>(smem + L.order1);
     v.path1 = reinterpret_cast<int32_t*>(smem + L.path1);
     v.path2 = reinterpret_cast<int32_t*>(smem + L.path2);
+    v.ppos1 = reinterpret_cast<int32_t*>(smem + L.ppos1);
+    v.ppos2 = reinterpret_cast<int32_t*>(smem + L.ppos2);
     v.rec1 = reinterpret_cast<McfNode*>(smem + L.rec1);
     v.rec2 = reinterpret_cast<McfNode*>(smem + L.rec2);
     v.seg = reinterpret_cast<McfSeg*>(smem + L.seg);
@@ -585,11 +618,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         }
         __syncthreads();
         const int go = s_go;
-        if (go == 2) mcf_pivot_scan(v, &s_cy, &s_acc, reinterpret_cast<int32_t*>(v.seg), INT32_MAX, threadIdx.x, kSmallThreads);
-        if (go && threadIdx.x == 0 && c->status == MCF_RUNNING) mcf_pivot_decide(v, s_cy);
+        if (go == 2) mcf_pivot_scan(v, mcf_view_paths(v), 0, &s_cy, &s_acc, reinterpret_cast<int32_t*>(v.seg), INT32_MAX, threadIdx.x, kSmallThreads);
+        if (go && threadIdx.x == 0 && c->status == MCF_RUNNING) mcf_pivot_decide(v, mcf_view_paths(v), s_cy);
         STAMP(3);
         __syncthreads();
-        mcf_pivot_finish(v, threadIdx.x, kSmallThreads);
+        mcf_pivot_finish(v, mcf_view_paths(v), threadIdx.x, kSmallThreads);
         __syncthreads();
         STAMP(4);
         // ---- apply: block permutation of the preorder array + potential shift
@@ -656,7 +689,7 @@ struct mcf_handle {
     McfArcW* d_arcw = nullptr;
     int64_t* d_pi = nullptr;
     McfNode* d_node = nullptr;
-    int32_t *d_order0 = nullptr, *d_order1 = nullptr, *d_path1 = nullptr, *d_path2 = nullptr;
+    int32_t *d_order0 = nullptr, *d_order1 = nullptr, *d_path1 = nullptr, *d_path2 = nullptr, *d_ppos1 = nullptr, *d_ppos2 = nullptr;
     McfNode *d_rec1 = nullptr, *d_rec2 = nullptr;
     int64_t *d_rcache = nullptr, *d_adj_off = nullptr, *d_adj = nullptr;
     int32_t *d_pos0 = nullptr, *d_pos1 = nullptr, *d_psz0 = nullptr, *d_psz1 = nullptr;
@@ -859,7 +892,7 @@ void free_all(mcf_handle* h) {
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
-    (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
+    (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
     (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1);
     (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
@@ -958,6 +991,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     }
     if ((e = dalloc(&h->d_path1, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_path2, N)) != hipSuccess) return fail("hipMalloc path", e);
+    if ((e = dalloc(&h->d_ppos1, N)) != hipSuccess) return fail("hipMalloc path", e);
+    if ((e = dalloc(&h->d_ppos2, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_rec1, N)) != hipSuccess) return fail("hipMalloc rec", e);
     if ((e = dalloc(&h->d_rec2, N)) != hipSuccess) return fail("hipMalloc rec", e);
     if ((e = dalloc(&h->d_seg, 2 * N + 2)) != hipSuccess) return fail("hipMalloc seg", e);
@@ -979,7 +1014,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
     v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
     v.psz[0] = h->d_psz0; v.psz[1] = h->d_psz1;
-    v.path1 = h->d_path1; v.path2 = h->d_path2; v.rec1 = h->d_rec1; v.rec2 = h->d_rec2; v.seg = h->d_seg; v.ctx = h->d_ctx;
+    v.path1 = h->d_path1; v.path2 = h->d_path2; v.ppos1 = h->d_ppos1; v.ppos2 = h->d_ppos2; v.rec1 = h->d_rec1; v.rec2 = h->d_rec2; v.seg = h->d_seg; v.ctx = h->d_ctx;
 
     {
         // LDS plan of the fused small-instance path (every offset a multiple of 16)
@@ -992,11 +1027,11 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         L.arcw = take((uint64_t)im.arcw.size() * 16); L.pi = take(Nn * 8); L.node = take(Nn * 16);
         L.order0 = take(Nn * 4); L.order1 = take(Nn * 4); L.pos0 = take(Nn * 4); L.pos1 = take(Nn * 4);
         L.psz0 = take(scan_ok ? Nn * 4 : 0); L.psz1 = take(scan_ok ? Nn * 4 : 0);
-        L.path1 = take(Nn * 4); L.path2 = take(Nn * 4);
+        L.path1 = take(Nn * 4); L.path2 = take(Nn * 4); L.ppos1 = take(Nn * 4); L.ppos2 = take(Nn * 4);
         L.rec1 = take(Nn * 16); L.rec2 = take(Nn * 16);
         L.seg = take((2 * Nn + 2) * sizeof(McfSeg)); L.ctx = take(sizeof(McfCtx));
         L.total = off;
-        const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 112 + 4096;
+        const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 120 + 4096;
         h->small = !opt.no_fused && !opt.profile && h->shards == 1 && need < 150 * 1024 && L.total <= 158 * 1024;
         if (h->small) {
             hipError_t fe = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small),
@@ -1365,6 +1400,13 @@ int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident) {
 #ifdef MCF_STAMPS
 int mcf_debug_stamps(mcf_handle* h, unsigned long long* out8) {
     HIP_TRY(h, hipMemcpy(out8, h->d_rec1, 64, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
+// k_pivot phase stamps (24 slots, [23] = launches that pivoted); clear = 1 zeroes them afterwards
+int mcf_debug_pivot_stamps(mcf_handle* h, unsigned long long* out24, int clear) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_pivot_stamps), 24 * 8));
+    if (clear) { unsigned long long z[24] = {0}; HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(g_pivot_stamps), z, 24 * 8)); }
     return MCF_OK;
 }
 #endif

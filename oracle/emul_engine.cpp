@@ -20,7 +20,7 @@ namespace {
 
 struct Emul {
     McfHostImage im;
-    std::vector<int32_t> order1, path1, path2, pos1, psz1;
+    std::vector<int32_t> order1, path1, path2, pos1, psz1, ppos1, ppos2;
     std::vector<McfNode> rec1, rec2;
     std::vector<McfSeg> seg;
     McfCtx ctx;
@@ -36,6 +36,8 @@ void bind(Emul& e) {
     e.pos1 = im.pos;
     e.path1.assign(im.n_nodes, 0);
     e.path2.assign(im.n_nodes, 0);
+    e.ppos1.assign(im.n_nodes, 0);
+    e.ppos2.assign(im.n_nodes, 0);
     e.rec1.assign(im.n_nodes, McfNode{0, 0, 0, 0});
     e.rec2.assign(im.n_nodes, McfNode{0, 0, 0, 0});
     e.seg.assign(2 * (size_t)im.n_nodes + 2, McfSeg{0, 0, 0, 0});
@@ -58,6 +60,8 @@ void bind(Emul& e) {
     v.order[1] = e.order1.data();
     v.path1 = e.path1.data();
     v.path2 = e.path2.data();
+    v.ppos1 = e.ppos1.data();
+    v.ppos2 = e.ppos2.data();
     v.rec1 = e.rec1.data();
     v.rec2 = e.rec2.data();
     v.seg = e.seg.data();

@@ -1,0 +1,26 @@
+"""Diagnostic: phase shares inside k_pivot (build: hipcc -DMCF_STAMPS ... -o scripts/libmcf_stamps.so)."""
+import ctypes, os, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+os.environ["MCF_HIP_LIB"] = str(ROOT / "scripts" / "libmcf_stamps.so")
+sys.path.insert(0, str(ROOT))
+import numpy as np
+from network_flow_solver_amd import engine, generators
+names = ["stage ctx+cand", "minor key + argmax", "accounting+begin", "cycle_init + barrier", "scan: setup", "scan: rounds", "scan: hit pass",
+         "scan: reduce+merge", "decide", "barrier+finish", "publish ctx"]
+for name, rule, cap in (("netgen_8_10a", 0, 10**9), ("netgen_8_14a", 0, 10**9), ("netgen_8_14a", 2, 10**9), ("goto_8_16a", 0, 60000)):
+    inst = generators.named_instance(name)
+    eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
+    out = (ctypes.c_ulonglong * 24)()
+    eng._lib.mcf_debug_pivot_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    eng._lib.mcf_debug_pivot_stamps(eng._h, out, 1)
+    eng.solve(max_pivots=cap)
+    st = eng.stats()
+    eng._lib.mcf_debug_pivot_stamps(eng._h, out, 1)
+    v = np.array(list(out), dtype=np.float64)
+    launches = max(v[23], 1)
+    print(f"{name} rule {rule}: pivots {st['pivots']} launches {int(launches)} ticks/launch {v[:11].sum() / launches:.0f} "
+          f"(solve {1e6 * st['solve_seconds'] / max(st['pivots'], 1):.2f} us/pivot)")
+    for n, x in zip(names, v[:11]):
+        print(f"   {n:22s} per launch {x / launches:9.1f}  share {100 * x / v[:11].sum():5.1f}%")
+    eng.close()
