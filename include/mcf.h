@@ -83,6 +83,9 @@ typedef struct mcf_options {
     int32_t no_rcache;       /* 1 = never keep reduced costs resident: always price by gathering potentials */
     int32_t cycle_scan;      /* cycle search: 0 = auto, -1 = always climb parent pointers, k >= 1 = climb k - 1 round
                                 trips, then finish by the position-space scan (1 = scan only) */
+    int32_t mid_loop;        /* persistent single-workgroup pivot loop for mid-size instances (k_solve_mid):
+                                0 = auto (by size and rule), -1 = never, 1 = whenever the handle allows it */
+    int32_t reserved;
 } mcf_options;
 
 typedef struct mcf_stats {
@@ -107,7 +110,8 @@ typedef struct mcf_stats {
     int64_t artificial_flow;  /* flow still on artificial arcs (> 0 at optimality = infeasible, simplex.py:1573-1624);
                                  -1 when mcf_get_result was asked for neither status, objective nor flow */
     int64_t pricing_mode;     /* 0 = gather sweep (k_price), 1 = resident reduced costs (k_price_rc + k_rcupd),
-                                 2 = fused LDS-resident pivot loop (k_solve_small) */
+                                 2 = fused LDS-resident pivot loop (k_solve_small),
+                                 3 = persistent single-workgroup loop over global memory (k_solve_mid) */
     int64_t cycle_scans;      /* pivots whose cycle was completed by the position-space scan */
     int64_t scan_rounds;      /* chunk iterations of those scans */
 } mcf_stats;

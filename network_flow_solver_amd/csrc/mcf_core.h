@@ -289,13 +289,13 @@ struct McfCycle {
 
 // Accumulators of the team-wide scan (LDS on the device).
 struct McfScanAcc {
-    int64_t r1, r2;        // smallest residual met by the scan on either side
-    int32_t i1, i2;        // path index that goes with it (side 1: lowest, side 2: highest among ties)
     int32_t jpos[2];       // preorder position of the deepest common ancestor met so far, -1: none yet
                            // (one slot per round parity: a round needs a single barrier)
     int32_t nhits;         // one-sided ancestors noted so far
     int32_t jnode;         // the join and its record (fetched while the hit pass runs)
     McfNode join;
+    int64_t wr1[16], wr2[16];  // per-wave results of the ratio reduction
+    int32_t wi1[16], wi2[16];
 };
 
 // Step 1 (one lane): bookkeeping + the entering arc.  Returns false when there is nothing to pivot on
@@ -434,28 +434,40 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, McfCycle* cy, int32_t budget) {
 // cy->w (first side) and vice versa; common ancestors lie at lower positions than all of them and
 // the join is the common ancestor with the highest position.
 //   rounds:  the team sweeps the positions downwards from max(pos[u], pos[w]) in chunks of
-//            nlanes * MCF_SCAN_K coalesced 4-byte loads and stops after the first chunk that holds a
-//            common ancestor (one barrier per round; position 0, the root, ends the sweep at the latest).
-//            One-sided ancestors are only noted (position + side) in a hit list.
+//            nlanes * 16 (one 16-byte load of four sizes per lane, four of them in flight) and stops after
+//            the first chunk that holds a common ancestor (one barrier per round; position 0, the root, ends
+//            the sweep at the latest).  One-sided ancestors are only noted (position + side) in a hit list.
 //   hits:    one dense pass over the list: node id, record, arc -> three dependent loads for the whole
 //            cycle, whatever its length.  A found ancestor a of u goes to path index
 //            n1 + depth[u] - depth[a] (the depth field makes a compaction unnecessary), its record next
 //            to it -- exactly what the climb would have recorded.
 //   ratio:   every lane keeps the best residual of the elements it met (side 1: lowest index among
-//            ties, side 2: highest -- the climb's `<` / `<=`); two team-wide atomic minima + one tie
-//            pass combine them.
-#define MCF_SCAN_K 16
+//            ties, side 2: highest -- the climb's `<` / `<=`); hit t is handled by lane t, so only the
+//            first ceil(nhits / 64) waves hold anything: they reduce by shuffles, lane 0 combines their results.
+#define MCF_SCAN_GROUPS 4  // 16-byte loads in flight per lane and round
 struct McfScanBest { int64_t b1r, b2r; int32_t b1i, b2i; };
+
+MCF_HD void mcf_scan_best_merge(McfScanBest* a, int64_t r1, int32_t i1, int64_t r2, int32_t i2) {
+    if (i1 >= 0 && (a->b1i < 0 || r1 < a->b1r || (r1 == a->b1r && i1 < a->b1i))) { a->b1r = r1; a->b1i = i1; }
+    if (i2 >= 0 && (a->b2i < 0 || r2 < a->b2r || (r2 == a->b2r && i2 > a->b2i))) { a->b2r = r2; a->b2i = i2; }
+}
+
+// lane 0 of the thread-0 section that precedes the scan: reset the accumulators (saves the scan a barrier)
+MCF_HD void mcf_scan_init(McfScanAcc* acc) {
+    acc->jpos[0] = -1; acc->jpos[1] = -1;
+    acc->nhits = 0;
+}
 
 // The dense pass over the hit list: node id, record, tree arc of every one-sided ancestor -> its slot in
 // the path buffers `pb`, and this lane's best residual per side.
 MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_t* ord, const int32_t* hits,
                               int32_t hits_cap, const int32_t* spill, int32_t nhits, int32_t base1, int32_t base2,
                               int32_t du, int32_t dw, int32_t lane, int32_t nlanes, McfScanBest* out) {
-    int64_t b1r = INT64_MAX, b2r = INT64_MAX;
+    int64_t b1r = 0, b2r = 0;
     int32_t b1i = -1, b2i = -1;
     for (int32_t t = lane; t < nhits; t += nlanes) {
-        const int32_t hrec = t < hits_cap ? hits[t] : spill[t - hits_cap];
+        int32_t hrec;
+        if (t < hits_cap) hrec = hits[t]; else hrec = spill[t - hits_cap];
         const int32_t nd = ord[hrec >> 1];
         const McfNode rec = v.node[nd];
         const McfArcW a = v.arcw[rec.pred >> 1];
@@ -465,63 +477,82 @@ MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_
             pb.rec1[idx] = rec;
             pb.ppos1[idx] = hrec >> 1;
             const int64_t r = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
-            if (r < b1r || (r == b1r && idx < b1i)) { b1r = r; b1i = idx; }
+            if (b1i < 0 || r < b1r || (r == b1r && idx < b1i)) { b1r = r; b1i = idx; }
         } else {
             const int32_t idx = base2 + dw - rec.depth;
             pb.path2[idx] = nd;
             pb.rec2[idx] = rec;
             pb.ppos2[idx] = hrec >> 1;
             const int64_t r = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
-            if (r < b2r || (r == b2r && idx > b2i)) { b2r = r; b2i = idx; }
+            if (b2i < 0 || r < b2r || (r == b2r && idx > b2i)) { b2r = r; b2i = idx; }
         }
     }
     out->b1r = b1r; out->b2r = b2r; out->b1i = b1i; out->b2i = b2i;
 }
+
 // `hits` holds the first `hits_cap` entries of the hit list (LDS on the device), the scratch behind v.seg the rest.
 // `sp`: small buffers of `small_cap` entries each (LDS on the device; cap 0 = none); a cycle found by the
 // scan alone that fits is recorded there (cy->small = 1), which spares the decide / finish passes a
-// global round trip per look-up.
+// global round trip per look-up.  The caller has run mcf_scan_init(acc) before the barrier in front of this call.
 MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_cap, McfCycle* cy, McfScanAcc* acc,
                            int32_t* hits, int32_t hits_cap, int32_t lane, int32_t nlanes) {
     McfCtx* c = v.ctx;
     const int32_t* ord = c->cur ? v.order[1] : v.order[0];
     const int32_t* psz = c->cur ? v.psz[1] : v.psz[0];
     int32_t* spill = reinterpret_cast<int32_t*>(v.seg);  // scratch the finish pass only fills later; <= n_nodes entries
-    if (lane == 0) {
-        acc->r1 = INT64_MAX; acc->r2 = INT64_MAX;
-        acc->i1 = INT32_MAX; acc->i2 = -1;
-        acc->jpos[0] = -1; acc->jpos[1] = -1;
-        acc->nhits = 0;
-    }
     const int32_t pu = cy->pu, pw = cy->pw, du = cy->ru.depth, dw = cy->rw.depth;
     const int32_t base1 = cy->n1, base2 = cy->n2;
-    MCF_TEAM_BARRIER();
     MCF_PSTAMP(4);
-    int32_t top = (pu > pw ? pu : pw) + 1;  // exclusive
+    // groups of four positions, aligned; psz[] is padded so that the group holding max(pu, pw) can be read whole
+    int32_t top = (((pu > pw ? pu : pw) + 1) + 3) & ~3;  // exclusive
     int32_t par = 0, rounds = 0, jpos = -1;
     for (;;) {
-        const int32_t lo = top - nlanes * MCF_SCAN_K;
-        int32_t sz[MCF_SCAN_K];
+        const int32_t lo = top - nlanes * 4 * MCF_SCAN_GROUPS;
+        int32_t sz[MCF_SCAN_GROUPS][4];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int k = 0; k < MCF_SCAN_K; ++k) {
-            const int32_t i = lo + k * nlanes + lane;
-            sz[k] = i >= 0 ? psz[i] : 0;
+        for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
+            const int32_t slice = lo + k * nlanes * 4;  // uniform
+            const int32_t i = slice + lane * 4;
+            sz[k][0] = sz[k][1] = sz[k][2] = sz[k][3] = 0;
+            if (slice + nlanes * 4 <= 0) continue;      // the whole slice lies below position 0 (small trees: most do)
+            if (i >= 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                const int4 q = *reinterpret_cast<const int4*>(psz + i);
+                sz[k][0] = q.x; sz[k][1] = q.y; sz[k][2] = q.z; sz[k][3] = q.w;
+#else
+                for (int e = 0; e < 4; ++e) sz[k][e] = psz[i + e];
+#endif
+            }
         }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int k = 0; k < MCF_SCAN_K; ++k) {
-            const int32_t i = lo + k * nlanes + lane;
-            if (i < 0) continue;
-            const bool au = i <= pu && pu - i < sz[k];
-            const bool aw = i <= pw && pw - i < sz[k];
-            if (au && aw) MCF_ATOMIC_MAX32(&acc->jpos[par], i);
-            else if (au || aw) {
-                const int32_t slot = MCF_ATOMIC_ADD32(&acc->nhits, 1);
-                const int32_t hrec = (i << 1) | (aw ? 1 : 0);
-                if (slot < hits_cap) hits[slot] = hrec; else spill[slot - hits_cap] = hrec;
+        for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
+            const int32_t slice = lo + k * nlanes * 4;
+            if (slice + nlanes * 4 <= 0) continue;
+            const int32_t i0 = slice + lane * 4;
+            // i <= p < i + size  <=>  unsigned(p - i) < unsigned(size)   (sizes are positive; 0 marks "no position").
+            // Branch-free test of the four positions first: ancestors are rare.
+            uint32_t mu = 0, mw = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int e = 0; e < 4; ++e) {
+                mu |= (uint32_t)((uint32_t)(pu - i0 - e) < (uint32_t)sz[k][e]) << e;
+                mw |= (uint32_t)((uint32_t)(pw - i0 - e) < (uint32_t)sz[k][e]) << e;
+            }
+            if (!(mu | mw)) continue;
+            for (int e = 0; e < 4; ++e) {
+                const bool au = (mu >> e) & 1, aw = (mw >> e) & 1;
+                const int32_t i = i0 + e;
+                if (au && aw) MCF_ATOMIC_MAX32(&acc->jpos[par], i);
+                else if (au || aw) {
+                    const int32_t slot = MCF_ATOMIC_ADD32(&acc->nhits, 1);
+                    const int32_t hrec = (i << 1) | (aw ? 1 : 0);
+                    if (slot < hits_cap) hits[slot] = hrec; else spill[slot - hits_cap] = hrec;
+                }
             }
         }
         MCF_TEAM_BARRIER();
@@ -549,19 +580,29 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
     McfScanBest best;
     if (small) mcf_scan_hit_pass(v, sp, ord, hits, hits_cap, spill, nhits, base1, base2, du, dw, lane, nlanes, &best);
     else mcf_scan_hit_pass(v, mcf_view_paths(v), ord, hits, hits_cap, spill, nhits, base1, base2, du, dw, lane, nlanes, &best);
-    const int64_t b1r = best.b1r, b2r = best.b2r;
-    const int32_t b1i = best.b1i, b2i = best.b2i;
     MCF_PSTAMP(6);
-    if (b1i >= 0) MCF_ATOMIC_MIN64(&acc->r1, b1r);
-    if (b2i >= 0) MCF_ATOMIC_MIN64(&acc->r2, b2r);
-    MCF_TEAM_BARRIER();
-    if (b1i >= 0 && b1r == acc->r1) MCF_ATOMIC_MIN32(&acc->i1, b1i);
-    if (b2i >= 0 && b2r == acc->r2) MCF_ATOMIC_MAX32(&acc->i2, b2i);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // hit t was handled by lane t % nlanes: waves beyond ceil(nhits / 64) hold nothing
+    const int32_t wave = lane >> 6, nwaves_hit = nhits >= nlanes ? nlanes >> 6 : (nhits + 63) >> 6;
+    if (wave < nwaves_hit) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int64_t r1 = (int64_t)__shfl_xor((long long)best.b1r, off, 64), r2 = (int64_t)__shfl_xor((long long)best.b2r, off, 64);
+            const int32_t i1 = __shfl_xor(best.b1i, off, 64), i2 = __shfl_xor(best.b2i, off, 64);
+            mcf_scan_best_merge(&best, r1, i1, r2, i2);
+        }
+        if ((lane & 63) == 0) { acc->wr1[wave] = best.b1r; acc->wr2[wave] = best.b2r; acc->wi1[wave] = best.b1i; acc->wi2[wave] = best.b2i; }
+    }
     MCF_TEAM_BARRIER();
     if (lane == 0) {
+        best.b1i = -1; best.b2i = -1;
+        for (int32_t q = 0; q < nwaves_hit; ++q) mcf_scan_best_merge(&best, acc->wr1[q], acc->wi1[q], acc->wr2[q], acc->wi2[q]);
+    }
+#endif
+    if (lane == 0) {
         // merge with what the climb found: its elements have the lower path indices
-        if (acc->i1 != INT32_MAX && acc->r1 < cy->d1) { cy->d1 = acc->r1; cy->k1 = acc->i1; }
-        if (acc->i2 >= 0 && acc->r2 <= cy->d2) { cy->d2 = acc->r2; cy->k2 = acc->i2; }
+        if (best.b1i >= 0 && best.b1r < cy->d1) { cy->d1 = best.b1r; cy->k1 = best.b1i; }
+        if (best.b2i >= 0 && best.b2r <= cy->d2) { cy->d2 = best.b2r; cy->k2 = best.b2i; }
         const int32_t jn = acc->jnode;
         const McfNode rj = acc->join;
         cy->n1 = base1 + du - rj.depth;
@@ -659,6 +700,7 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     if (!mcf_pivot_climb(v, &cy, v.psz[0] ? v.ctx->climb_budget : INT32_MAX)) return;
     if (cy.u != cy.w) {
         McfScanAcc acc;
+        mcf_scan_init(&acc);
         mcf_pivot_scan(v, mcf_view_paths(v), 0, &cy, &acc, nullptr, 0, 0, 1);
         if (v.ctx->status != MCF_RUNNING) return;
     }

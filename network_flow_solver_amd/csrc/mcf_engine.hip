@@ -41,6 +41,8 @@ namespace {
 constexpr int kPriceThreads = 256;
 constexpr int kPivotThreads = 1024;  // one workgroup: final arg-max, cycle search (climb by one lane / scan by all), finish
 constexpr int kReduceThreads = 256;
+constexpr int kMidMaxNodes = 1 << 13;        // persistent single-workgroup loop (k_solve_mid): auto up to this many nodes ...
+constexpr int kMidMaxArcsPerPivot = 1 << 14;  // ... and this many arcs priced inside the loop per pivot
 constexpr int kScanMaxNodes = 1 << 20;  // beyond this the position-space sizes are not kept: the cycle is always climbed
 constexpr int kApplyThreads = 256;
 constexpr int kMaxPriceBlocks = 2048;  // 8 workgroups per CU on 256 CUs
@@ -62,13 +64,30 @@ __device__ __forceinline__ int64_t readlane64(int64_t x, int lane) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// Wave-wide max of a signed 64-bit value with DPP moves (row-local butterflies, then the two row
+// broadcasts of gfx9) instead of ds_bpermute shuffles: ~6 x (2 dpp movs + a 64-bit compare/select) of a
+// few cycles each, versus twelve dependent trips through the LDS crossbar.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int64_t dpp_max_step(int64_t x) {
+    const int lo = (int)(uint32_t)x, hi = (int)(uint32_t)((uint64_t)x >> 32);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const int64_t o = (int64_t)(((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo);
+    return o > x ? o : x;
+}
+
+__device__ __forceinline__ int64_t wave_max64(int64_t x) {
+    x = dpp_max_step<0xB1, 0xf>(x);   // quad_perm [1,0,3,2]
+    x = dpp_max_step<0x4E, 0xf>(x);   // quad_perm [2,3,0,1]
+    x = dpp_max_step<0x141, 0xf>(x);  // row_half_mirror
+    x = dpp_max_step<0x140, 0xf>(x);  // row_mirror: every lane of a row of 16 now holds the row's max
+    x = dpp_max_step<0x142, 0xa>(x);  // row_bcast15 into rows 1 and 3
+    x = dpp_max_step<0x143, 0xc>(x);  // row_bcast31 into rows 2 and 3: lane 63 holds the max of the wave
+    return readlane64(x, 63);
+}
+
 __device__ __forceinline__ void wave_argmax(int64_t& key, int64_t& arc) {
-    int64_t mx = key;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int64_t o = (int64_t)__shfl_xor((long long)mx, off, 64);
-        mx = o > mx ? o : mx;
-    }
+    const int64_t mx = wave_max64(key);
     uint64_t mask = __ballot(key == mx && key > 0);
     int64_t best = -1;
     while (mask) {  // uniform loop: one iteration unless several lanes tie on the key
@@ -278,15 +297,15 @@ constexpr int kMaxRcupdBlocks = 1024;
 // against the OLD positions (posbuf[cur], which this launch never writes) and T2 is enumerated
 // through the OLD order (order[cur][a0 .. a0+S)): the apply half writes order[cur^1],
 // posbuf[cur^1], pi and the depths of T2; the update half writes rcache.  One launch boundary less per pivot.
-__global__ __launch_bounds__(kRcupdThreads) void k_update(McfView v) {
-    const McfCtx c = *v.ctx;  // uniform: scalar loads
-    if (!c.apply) return;
-    const int64_t stride = (int64_t)gridDim.x * kRcupdThreads;
-    const int64_t tid = (int64_t)blockIdx.x * kRcupdThreads + threadIdx.x;
-    for (int64_t j = c.lo + tid; j < c.hi; j += stride) mcf_apply_one(v, c, (int32_t)j);
-    for (int64_t j = c.prev_lo + tid; j < c.prev_hi; j += stride)
-        if (j < c.lo || j >= c.hi) mcf_apply_one(v, c, (int32_t)j);
-
+// `c` is the control block (kernel argument memory / LDS); the pass is spread over `stride` lanes of which this
+// one is `tid`, and over `ngroups` 16-lane groups of which this lane belongs to `group` (sub-lane `sub`).
+__device__ __forceinline__ void update_pass(const McfView& v, const McfCtx& c, int64_t tid, int64_t stride, int64_t group,
+                                            int64_t ngroups, int32_t sub) {
+    const int32_t lo = c.lo, hi = c.hi, plo = c.prev_lo, phi = c.prev_hi;
+    for (int64_t j = lo + tid; j < hi; j += stride) mcf_apply_one(v, c, (int32_t)j);
+    for (int64_t j = plo + tid; j < phi; j += stride)
+        if (j < lo || j >= hi) mcf_apply_one(v, c, (int32_t)j);
+    if (!v.rcache) return;
     const int32_t a0 = c.t2_old, S = c.t2_size;
     const int64_t sigma = c.sigma;
     const int32_t* __restrict__ ord = c.cur ? v.order[1] : v.order[0];     // old order
@@ -294,9 +313,7 @@ __global__ __launch_bounds__(kRcupdThreads) void k_update(McfView v) {
     const int64_t* __restrict__ adj_off = v.adj_off;
     const int64_t* __restrict__ adj = v.adj;
     int64_t* __restrict__ rcache = v.rcache;
-    const int32_t sub = threadIdx.x & 15;
-    const int64_t ngroups = (int64_t)gridDim.x * (kRcupdThreads / 16);
-    for (int64_t t = (int64_t)blockIdx.x * (kRcupdThreads / 16) + (threadIdx.x >> 4); t < S; t += ngroups) {
+    for (int64_t t = group; t < S; t += ngroups) {
         const int32_t u = ord[a0 + t];
         const int64_t beg = adj_off[u], end = adj_off[u + 1];
         for (int64_t p = beg + sub; p < end; p += 16) {
@@ -306,6 +323,14 @@ __global__ __launch_bounds__(kRcupdThreads) void k_update(McfView v) {
             rcache[(int32_t)((uint32_t)ent >> 1)] += (ent & 1) ? sigma : -sigma;
         }
     }
+}
+
+__global__ __launch_bounds__(kRcupdThreads) void k_update(McfView v) {
+    const McfCtx c = *v.ctx;  // uniform: scalar loads
+    if (!c.apply) return;
+    update_pass(v, c, (int64_t)blockIdx.x * kRcupdThreads + threadIdx.x, (int64_t)gridDim.x * kRcupdThreads,
+                (int64_t)blockIdx.x * (kRcupdThreads / 16) + (threadIdx.x >> 4), (int64_t)gridDim.x * (kRcupdThreads / 16),
+                threadIdx.x & 15);
 }
 
 // ------------------------------------------------------------------ k_reduce (multi-GPU: local best -> 16 bytes)
@@ -331,37 +356,88 @@ __device__ unsigned long long g_pivot_stamps[24];
 constexpr int kHitsLds = 4096;   // hit-list entries kept in LDS (a longer cycle spills to global scratch)
 constexpr int kSmallPath = 512;  // cycles up to this many nodes are recorded in LDS instead of the global path scratch
 
+// LDS state of one pivoting workgroup (k_pivot, k_solve_mid)
+struct PivotShared {
+    McfCtx ctx;
+    McfCycle cy;
+    McfScanAcc acc;
+    int go;  // 0 = nothing to pivot on, 1 = the climb reached the join, 2 = the scan has to finish the cycle
+    int32_t hits[kHitsLds];
+    int32_t path[2][kSmallPath], ppos[2][kSmallPath];
+    McfNode rec[2][kSmallPath];
+};
+constexpr int kCtxWords = (int)(sizeof(McfCtx) / 4);
+static_assert(sizeof(McfCtx) % 4 == 0 && kCtxWords <= kPivotThreads, "control block staging");
+
+// From the chosen entering arc to the updated flows / tree records / apply descriptor.  `v.ctx` must point at
+// S.ctx; (key, arc) valid in thread 0; `priced` = arcs this pass evaluated (accounting).  All threads call it.
+__device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int64_t key, int64_t arc, int32_t rule,
+                                            int64_t priced) {
+    if (threadIdx.x == 0) {
+        McfCtx* c = v.ctx;
+        if (c->pivots < c->max_pivots) c->arcs_priced += priced;  // whole-job accounting: the arcs of this pass over ALL shards
+        int go = 0;
+        if (mcf_pivot_begin(v, key, arc, rule)) {
+            MCF_PSTAMP(2);
+            mcf_cycle_init(v, &S.cy);
+            // sequential part: at most climb_budget dependent round trips
+            if (mcf_pivot_climb(v, &S.cy, v.psz[0] ? c->climb_budget : INT32_MAX)) go = S.cy.u == S.cy.w ? 1 : 2;
+            if (go == 2) mcf_scan_init(&S.acc);
+        }
+        S.go = go;
+    }
+    __syncthreads();
+    MCF_PSTAMP(3);
+    const int go = S.go;
+    const McfPaths gp = mcf_view_paths(v);                                                    // cycle scratch in global memory
+    const McfPaths sp = McfPaths{S.path[0], S.path[1], S.rec[0], S.rec[1], S.ppos[0], S.ppos[1]};  // ... and in LDS
+    if (go == 2) mcf_pivot_scan(v, sp, kSmallPath, &S.cy, &S.acc, S.hits, kHitsLds, threadIdx.x, kPivotThreads);  // barriers inside
+    // S.cy.small is written by lane 0 at the very end of the scan: lane 0 may use it at once, the others after the barrier.
+    // Separate calls for the two scratch locations: each inlined copy works on one known address space.
+    if (go && threadIdx.x == 0 && S.ctx.status == MCF_RUNNING) {
+        if (S.cy.small) mcf_pivot_decide(v, sp, S.cy); else mcf_pivot_decide(v, gp, S.cy);
+    }
+    MCF_PSTAMP(8);
+    __syncthreads();
+    if (go && S.cy.small) mcf_pivot_finish(v, sp, threadIdx.x, kPivotThreads);  // array updates, one path element per lane
+    else mcf_pivot_finish(v, gp, threadIdx.x, kPivotThreads);
+    MCF_PSTAMP(9);
+}
+
+// arcs one Devex pass looks at (all shards): block k of every bucket
+__device__ __forceinline__ int64_t devex_block_arcs(const McfView& v, const McfCtx& c) {
+    int64_t priced = 0;
+    for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+        int64_t lo, hi;
+        mcf_bucket_slice(v.bucket_off, x, 0, 1, c.block_index, c.num_blocks, &lo, &hi);
+        priced += hi - lo;
+    }
+    return priced;
+}
+
 __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCand* __restrict__ cand, int ncand,
                                                           int32_t rule, int have_sweep) {
-    __shared__ McfCtx s_ctx;
-    __shared__ McfCycle s_cy;
-    __shared__ McfScanAcc s_acc;
-    __shared__ int s_go;  // 0 = nothing to pivot on, 1 = the climb reached the join, 2 = the scan has to finish the cycle
-    __shared__ int32_t s_hits[kHitsLds];
-    __shared__ int32_t s_path[2][kSmallPath], s_ppos[2][kSmallPath];
-    __shared__ McfNode s_rec[2][kSmallPath];
-    constexpr int kCtxWords = (int)(sizeof(McfCtx) / 4);
-    static_assert(sizeof(McfCtx) % 4 == 0 && kCtxWords <= kPivotThreads, "control block staging");
+    __shared__ PivotShared S;
 #ifdef MCF_STAMPS
     if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = __builtin_amdgcn_s_memtime(); }
 #endif
-    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&s_ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
+    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&S.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
     McfCand first = McfCand{0, -1};
     if ((int)threadIdx.x < ncand) first = cand[threadIdx.x];  // in flight together with the control block
     __syncthreads();
     McfView v = g;
-    v.ctx = &s_ctx;
+    v.ctx = &S.ctx;
     MCF_PSTAMP(0);
     // candidate-list rule: slots without a pricing launch in front (have_sweep == 0) can only run
     // minor iterations; once the list is exhausted they idle until the next slot that sweeps
-    if (s_ctx.status != MCF_RUNNING || (!have_sweep && s_ctx.minor_left <= 0)) {
+    if (S.ctx.status != MCF_RUNNING || (!have_sweep && S.ctx.minor_left <= 0)) {
         if (threadIdx.x == 0) g.ctx->apply = 0;
         return;
     }
     int64_t key = 0, arc = -1;
     // candidate-list rule, minor iteration: no sweep ran; the listed arcs are re-priced here
     // against the current state (resident reduced cost or potentials)
-    const bool minor = rule == MCF_RULE_CANDIDATE_LIST && s_ctx.minor_left > 0;
+    const bool minor = rule == MCF_RULE_CANDIDATE_LIST && S.ctx.minor_left > 0;
     for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
         const McfCand cd = i == (int)threadIdx.x ? first : cand[i];
         const int64_t kk = minor ? mcf_minor_key(v, cd.arc) : cd.key;
@@ -373,52 +449,121 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
         block_argmax<kPivotThreads>(key, arc);
     }
     MCF_PSTAMP(1);
-    if (threadIdx.x == 0) {
-        McfCtx* c = v.ctx;
-        if (c->pivots < c->max_pivots) {
-            // whole-job accounting: the arcs of this pass over ALL shards
-            int64_t priced = minor ? ncand : v.m;  // full sweep: every arc (no 64-bit divisions on the hot path)
-            if (rule == MCF_RULE_DEVEX_BLOCK && c->num_blocks > 1) {
-                priced = 0;
-                for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
-                    int64_t lo, hi;
-                    mcf_bucket_slice(v.bucket_off, x, 0, 1, c->block_index, c->num_blocks, &lo, &hi);
-                    priced += hi - lo;
-                }
-            }
-            c->arcs_priced += priced;
-        }
-        int go = 0;
-        if (mcf_pivot_begin(v, key, arc, rule)) {
-            MCF_PSTAMP(2);
-            mcf_cycle_init(v, &s_cy);
-            // sequential part: at most climb_budget dependent round trips
-            if (mcf_pivot_climb(v, &s_cy, v.psz[0] ? c->climb_budget : INT32_MAX)) go = s_cy.u == s_cy.w ? 1 : 2;
-        }
-        s_go = go;
-    }
-    __syncthreads();
-    MCF_PSTAMP(3);
-    const int go = s_go;
-    const McfPaths gp = mcf_view_paths(v);                                                    // cycle scratch in global memory
-    const McfPaths sp = McfPaths{s_path[0], s_path[1], s_rec[0], s_rec[1], s_ppos[0], s_ppos[1]};  // ... and in LDS
-    if (go == 2) mcf_pivot_scan(v, sp, kSmallPath, &s_cy, &s_acc, s_hits, kHitsLds, threadIdx.x, kPivotThreads);  // barriers inside
-    // s_cy.small is written by lane 0 at the very end of the scan: lane 0 may use it at once, the others after the barrier.
-    // Separate calls for the two scratch locations: each inlined copy works on one known address space.
-    if (go && threadIdx.x == 0 && s_ctx.status == MCF_RUNNING) {
-        if (s_cy.small) mcf_pivot_decide(v, sp, s_cy); else mcf_pivot_decide(v, gp, s_cy);
-    }
-    MCF_PSTAMP(8);
-    __syncthreads();
-    if (go && s_cy.small) mcf_pivot_finish(v, sp, threadIdx.x, kPivotThreads);  // array updates, one path element per lane
-    else mcf_pivot_finish(v, gp, threadIdx.x, kPivotThreads);
-    MCF_PSTAMP(9);
+    int64_t priced = minor ? ncand : v.m;  // full sweep: every arc (no 64-bit divisions on the hot path)
+    if (threadIdx.x == 0 && rule == MCF_RULE_DEVEX_BLOCK && S.ctx.num_blocks > 1) priced = devex_block_arcs(v, S.ctx);
+    pivot_core(v, S, key, arc, rule, priced);
     // publish the control block for the apply / pricing launches that follow (finish only reads it)
-    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&s_ctx)[threadIdx.x];
+    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&S.ctx)[threadIdx.x];
 #ifdef MCF_STAMPS
     __syncthreads();
     MCF_PSTAMP(10);
     if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i]; g_pivot_stamps[23] += 1; }
+#endif
+}
+
+// ------------------------------------------------------------------ k_solve_mid: persistent single-workgroup pivot loop, state in global memory
+// Between two kernels of the three-kernel path every first touch of the tree arrays is a miss to the memory-side
+// cache (the previous kernel wrote them from other CUs / XCDs): ~0.7 us per dependent round trip, ~12 of them in
+// k_pivot alone.  For mid-size instances one workgroup can do the WHOLE pivot -- pricing of a Devex block (or, for
+// the candidate-list rule, re-pricing the list), cycle scan, finish, block permutation + potential shift, resident
+// reduced-cost update -- and then nothing crosses a kernel boundary: the state stays in this CU's L1 / this XCD's
+// L2 for as many pivots as the rule allows.  Same core functions, same arc sets and tie rules as the other paths,
+// hence the identical pivot sequence.
+//   Devex block / small Dantzig:  one launch runs until optimal / pivot limit.
+//   candidate list:               the launch ends when a full sweep is due (k_price_rc over the whole grid builds
+//                                 the next list); `fresh` says such a sweep ran right before this launch.
+constexpr int kMidTabBlocks = 32;
+
+__global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t rule, const McfCand* __restrict__ cand,
+                                                              int ncand, int fresh, int max_iters) {
+    __shared__ PivotShared S;
+    __shared__ int64_t s_lo[kMidTabBlocks * MCF_NUM_BUCKETS], s_hi[kMidTabBlocks * MCF_NUM_BUCKETS];
+#ifdef MCF_STAMPS
+    if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = __builtin_amdgcn_s_memtime(); }
+    __syncthreads();
+#endif
+    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&S.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
+    __syncthreads();
+    McfView v = g;
+    v.ctx = &S.ctx;
+    const bool listing = rule == MCF_RULE_CANDIDATE_LIST;
+    // the sweep in front of this launch was a no-op if the list was still live (k_price_rc, use_block == 2)
+    bool have_fresh = listing && fresh && S.ctx.minor_left <= 0 && S.ctx.status == MCF_RUNNING;
+    const int64_t nb_all = rule == MCF_RULE_DEVEX_BLOCK ? S.ctx.num_blocks : 1;
+    const bool tabulated = nb_all <= kMidTabBlocks;
+    if (!listing) {
+        if (tabulated) {
+            for (int q = threadIdx.x; q < (int)nb_all * MCF_NUM_BUCKETS; q += kPivotThreads)
+                mcf_bucket_slice(g.bucket_off, q % MCF_NUM_BUCKETS, 0, 1, q / MCF_NUM_BUCKETS, nb_all, &s_lo[q], &s_hi[q]);
+        } else if (threadIdx.x < MCF_NUM_BUCKETS) {
+            mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, S.ctx.block_index, nb_all, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < max_iters; ++it) {
+        // uniform control values are read BEFORE a barrier: lane 0 rewrites them later in this very iteration
+        const int32_t status_now = S.ctx.status;
+        const int32_t minor_left = S.ctx.minor_left;
+        const int32_t row = tabulated && rule == MCF_RULE_DEVEX_BLOCK ? (int32_t)S.ctx.block_index * MCF_NUM_BUCKETS : 0;
+        __syncthreads();
+        if (status_now != MCF_RUNNING) break;
+        MCF_PSTAMP(0);
+        int64_t key = 0, arc = -1, priced = 0;
+        if (listing) {
+            const bool minor = minor_left > 0;
+            if (!minor && !have_fresh) break;  // a full sweep is due: back to the grid
+            have_fresh = false;
+            for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
+                const McfCand cd = cand[i];
+                const int64_t kk = minor ? mcf_minor_key(v, cd.arc) : cd.key;
+                if (mcf_cand_better(kk, cd.arc, key, arc)) { key = kk; arc = cd.arc; }
+            }
+            priced = minor ? ncand : v.m;
+            if (ncand <= 64) { if (threadIdx.x < 64) wave_argmax(key, arc); }
+            else block_argmax<kPivotThreads>(key, arc);
+        } else {
+            // the arc set of k_price_rc for shard 0 of 1: 128 lanes per head bucket, all eight buckets at once,
+            // streaming the resident reduced costs
+            constexpr int kPer = kPivotThreads / MCF_NUM_BUCKETS;
+            const int x = threadIdx.x / kPer, l = threadIdx.x % kPer;
+            const int64_t lo = s_lo[row + x], hi = s_hi[row + x];
+            const int64_t* __restrict__ rcache = v.rcache;
+            const int8_t* __restrict__ state = v.state;
+            for (int64_t i = lo + l; i < hi; i += kPer) {
+                const int32_t st = state[i];
+                if (!st) continue;
+                const int64_t viol = -(int64_t)st * rcache[i];
+                if (viol <= 0) continue;
+                int64_t kk = viol;
+                if (rule == MCF_RULE_DEVEX_BLOCK) {
+                    const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
+                    kk = __double_as_longlong(merit);
+                }
+                if (kk < key) continue;
+                const int64_t id = mcf_pack_arc(v.orig[i], i);
+                if (mcf_cand_better(kk, id, key, arc)) { key = kk; arc = id; }
+            }
+            if (threadIdx.x == 0)
+                for (int x2 = 0; x2 < MCF_NUM_BUCKETS; ++x2) priced += s_hi[row + x2] - s_lo[row + x2];
+            block_argmax<kPivotThreads>(key, arc);
+        }
+        MCF_PSTAMP(1);
+        pivot_core(v, S, key, arc, rule, priced);
+        __syncthreads();  // the finish pass's writes (records, sizes, segment table) before the apply pass reads them
+        if (S.ctx.apply) update_pass(v, S.ctx, threadIdx.x, kPivotThreads, threadIdx.x >> 4, kPivotThreads / 16, threadIdx.x & 15);
+        __syncthreads();
+        MCF_PSTAMP(10);
+#ifdef MCF_STAMPS
+        if (threadIdx.x == 0) mcf_stamp_acc[23] += 1;
+#endif
+        if (threadIdx.x == 0) S.ctx.apply = 0;
+        if (!listing && !tabulated && threadIdx.x < MCF_NUM_BUCKETS)
+            mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, S.ctx.block_index, nb_all, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
+    }
+    __syncthreads();
+    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&S.ctx)[threadIdx.x];
+#ifdef MCF_STAMPS
+    if (threadIdx.x == 0) for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i];
 #endif
 }
 
@@ -443,7 +588,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
 // mcf_apply_one) and copies the state back.  Same arc sets, same tie rule, same core functions
 // as the three-kernel path, so the pivot sequence is identical.
 struct SmallLayout {
-    uint32_t tail, head, cost, orig, state, weight, arcw, pi, node, order0, order1, pos0, pos1, psz0, psz1, path1, path2, ppos1, ppos2, rec1, rec2, seg, ctx, total;
+    uint32_t tail, head, cost, orig, state, weight, arcw, pi, node, order0, order1, pos0, pos1, path1, path2, ppos1, ppos2, rec1, rec2, seg, ctx, total;
 };
 
 constexpr int kSmallThreads = 1024;
@@ -501,8 +646,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     v.ctx = reinterpret_cast<McfCtx*>(smem + L.ctx);
     v.posbuf[0] = reinterpret_cast<int32_t*>(smem + L.pos0);
     v.posbuf[1] = reinterpret_cast<int32_t*>(smem + L.pos1);
-    v.psz[0] = g.psz[0] ? reinterpret_cast<int32_t*>(smem + L.psz0) : nullptr;
-    v.psz[1] = g.psz[0] ? reinterpret_cast<int32_t*>(smem + L.psz1) : nullptr;
+    v.psz[0] = nullptr;  // always the climb here (see the pivot step); mcf_create keeps no sizes for such a handle
+    v.psz[1] = nullptr;
 
     copy_words(smem + L.tail, g.tail, m_pad4);
     copy_words(smem + L.head, g.head, m_pad4);
@@ -517,7 +662,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     copy_words(smem + L.order1, g.order[1], N * 4u);
     copy_words(smem + L.pos0, g.posbuf[0], N * 4u);
     copy_words(smem + L.pos1, g.posbuf[1], N * 4u);
-    if (g.psz[0]) { copy_words(smem + L.psz0, g.psz[0], N * 4u); copy_words(smem + L.psz1, g.psz[1], N * 4u); }
     copy_words(smem + L.ctx, g.ctx, (uint32_t)sizeof(McfCtx));
     __syncthreads();
     STAMP(0);
@@ -542,9 +686,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     // those 8 arcs.  The list survives between launches in `list` (global).
     const bool listing = rule == MCF_RULE_CANDIDATE_LIST;
     __shared__ int64_t s_lk[MCF_NUM_BUCKETS], s_la[MCF_NUM_BUCKETS];
-    __shared__ McfCycle s_cy;
-    __shared__ McfScanAcc s_acc;
-    __shared__ int s_go;
     if (listing && threadIdx.x < MCF_NUM_BUCKETS) { s_lk[threadIdx.x] = list[threadIdx.x].key; s_la[threadIdx.x] = list[threadIdx.x].arc; }
     __syncthreads();
     for (;;) {
@@ -609,17 +750,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
                 for (int x = 0; x < MCF_NUM_BUCKETS; ++x) priced += s_hi[row + x] - s_lo[row + x];
                 c->arcs_priced += minor ? MCF_NUM_BUCKETS : priced;
             }
-            int go = 0;
-            if (mcf_pivot_begin(v, key, arc, rule)) {
-                mcf_cycle_init(v, &s_cy);
-                if (mcf_pivot_climb(v, &s_cy, v.psz[0] ? c->climb_budget : INT32_MAX)) go = s_cy.u == s_cy.w ? 1 : 2;
-            }
-            s_go = go;
+            // With the tree in LDS a climb step costs ~100 cycles: the one-lane walk (its state in registers) beats
+            // the workgroup-wide scan and its barriers (measured 130 K vs 116 K pivots/s on netgen_8_08a), so the
+            // LDS loop keeps no position-space sizes at all.
+            mcf_pivot_walk(v, key, arc, rule);
         }
-        __syncthreads();
-        const int go = s_go;
-        if (go == 2) mcf_pivot_scan(v, mcf_view_paths(v), 0, &s_cy, &s_acc, reinterpret_cast<int32_t*>(v.seg), INT32_MAX, threadIdx.x, kSmallThreads);
-        if (go && threadIdx.x == 0 && c->status == MCF_RUNNING) mcf_pivot_decide(v, mcf_view_paths(v), s_cy);
         STAMP(3);
         __syncthreads();
         mcf_pivot_finish(v, mcf_view_paths(v), threadIdx.x, kSmallThreads);
@@ -651,7 +786,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     copy_words(g.order[1], smem + L.order1, N * 4u);
     copy_words(g.posbuf[0], smem + L.pos0, N * 4u);
     copy_words(g.posbuf[1], smem + L.pos1, N * 4u);
-    if (g.psz[0]) { copy_words(g.psz[0], smem + L.psz0, N * 4u); copy_words(g.psz[1], smem + L.psz1, N * 4u); }
     copy_words(g.ctx, smem + L.ctx, (uint32_t)sizeof(McfCtx));
     if (listing && threadIdx.x < MCF_NUM_BUCKETS) list[threadIdx.x] = McfCand{s_lk[threadIdx.x], s_la[threadIdx.x]};
 #ifdef MCF_STAMPS
@@ -707,6 +841,7 @@ struct mcf_handle {
     int apply_blocks = 1;
     int32_t climb_budget = INT32_MAX;  // round trips the cycle climb may take before the scan takes over
     bool small = false;       // whole instance fits in LDS: fused single-workgroup pivot loop
+    bool mid = false;         // mid-size instance: persistent single-workgroup pivot loop over global memory (k_solve_mid)
     SmallLayout small_layout{};
     int64_t shard = 0, shards = 1;
     int64_t shard_arcs = 0;  // arcs of this rank's shard (all buckets)
@@ -829,6 +964,15 @@ void launch_apply(mcf_handle* h, hipStream_t s) {
 // would be a no-op anyway -- this just saves its launch boundary).
 void launch_pivot_triplet(mcf_handle* h, hipStream_t s, int slot = 0) {
     const int32_t rule = h->opt.rule;
+    if (h->mid) {
+        // candidate list: one grid sweep (a no-op while the list is live), then the persistent loop runs the major
+        // pivot and every minor pivot the list yields.  Other rules: the loop prices by itself until the solve ends.
+        const bool listing = rule == MCF_RULE_CANDIDATE_LIST;
+        if (listing) launch_price(h, s, h->view, rule, 1);
+        hipLaunchKernelGGL(k_solve_mid, dim3(1), dim3(kPivotThreads), 0, s, h->view, rule, h->d_cand, h->price_blocks,
+                           listing ? 1 : 0, listing ? mcf_minor_cap(h->price_blocks) + 2 : (1 << 22));
+        return;
+    }
     int have_sweep = 1;
     if (rule == MCF_RULE_CANDIDATE_LIST) have_sweep = slot % (mcf_minor_cap(h->price_blocks) + 1) == 0;
     if (have_sweep) launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG);
@@ -984,11 +1128,6 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     if ((e = dalloc(&h->d_order1, N)) != hipSuccess) return fail("hipMalloc order", e);
     if ((e = dalloc(&h->d_pos0, N)) != hipSuccess) return fail("hipMalloc pos", e);
     if ((e = dalloc(&h->d_pos1, N)) != hipSuccess) return fail("hipMalloc pos", e);
-    const bool scan_ok = opt.cycle_scan >= 0 && im.n_nodes <= kScanMaxNodes;  // -1: never scan
-    if (scan_ok) {
-        if ((e = dalloc(&h->d_psz0, N)) != hipSuccess) return fail("hipMalloc psz", e);
-        if ((e = dalloc(&h->d_psz1, N)) != hipSuccess) return fail("hipMalloc psz", e);
-    }
     if ((e = dalloc(&h->d_path1, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_path2, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_ppos1, N)) != hipSuccess) return fail("hipMalloc path", e);
@@ -1013,7 +1152,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     v.arcw = h->d_arcw; v.pi = h->d_pi; v.node = h->d_node;
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
     v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
-    v.psz[0] = h->d_psz0; v.psz[1] = h->d_psz1;
+    v.psz[0] = nullptr; v.psz[1] = nullptr;
     v.path1 = h->d_path1; v.path2 = h->d_path2; v.ppos1 = h->d_ppos1; v.ppos2 = h->d_ppos2; v.rec1 = h->d_rec1; v.rec2 = h->d_rec2; v.seg = h->d_seg; v.ctx = h->d_ctx;
 
     {
@@ -1026,18 +1165,25 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         L.state = take(mp); L.weight = take(opt.rule == MCF_RULE_DEVEX_BLOCK ? mp * 4 : 0);
         L.arcw = take((uint64_t)im.arcw.size() * 16); L.pi = take(Nn * 8); L.node = take(Nn * 16);
         L.order0 = take(Nn * 4); L.order1 = take(Nn * 4); L.pos0 = take(Nn * 4); L.pos1 = take(Nn * 4);
-        L.psz0 = take(scan_ok ? Nn * 4 : 0); L.psz1 = take(scan_ok ? Nn * 4 : 0);
         L.path1 = take(Nn * 4); L.path2 = take(Nn * 4); L.ppos1 = take(Nn * 4); L.ppos2 = take(Nn * 4);
         L.rec1 = take(Nn * 16); L.rec2 = take(Nn * 16);
         L.seg = take((2 * Nn + 2) * sizeof(McfSeg)); L.ctx = take(sizeof(McfCtx));
         L.total = off;
-        const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 120 + 4096;
+        const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 112 + 4096;
         h->small = !opt.no_fused && !opt.profile && h->shards == 1 && need < 150 * 1024 && L.total <= 158 * 1024;
         if (h->small) {
             hipError_t fe = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
             if (fe != hipSuccess) h->small = false;  // fall back to the three-kernel GPU path
         }
+    }
+    // position-space subtree sizes for the cycle scan: every handle but the LDS-resident ones
+    const bool scan_ok = opt.cycle_scan >= 0 && im.n_nodes <= kScanMaxNodes && !h->small;  // -1: never scan
+    if (scan_ok) {
+        if ((e = dalloc(&h->d_psz0, N + 4)) != hipSuccess) return fail("hipMalloc psz", e);  // +4: the scan reads whole groups of four
+        if ((e = dalloc(&h->d_psz1, N + 4)) != hipSuccess) return fail("hipMalloc psz", e);
+        if ((e = hipMemset(h->d_psz0, 0, (N + 4) * 4)) != hipSuccess || (e = hipMemset(h->d_psz1, 0, (N + 4) * 4)) != hipSuccess) return fail("hipMemset psz", e);
+        v.psz[0] = h->d_psz0; v.psz[1] = h->d_psz1;
     }
     // cycle search: how many round trips the one-lane climb takes before the workgroup-wide scan over
     // preorder positions finishes the cycle.  Auto = none: measured on MI355X (profiles/r01_f_*), scanning
@@ -1061,6 +1207,21 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         h->rcupd_blocks = (int)(rb < kMaxRcupdBlocks ? (rb > 0 ? rb : 1) : kMaxRcupdBlocks);
     } else {
         v.rcache = nullptr; v.adj_off = nullptr; v.adj = nullptr;
+    }
+    // persistent single-workgroup loop: the tree work of one pivot must be small enough for one CU, and so must
+    // the arcs it prices per pivot (a Devex block / the whole arc list for Dantzig; the candidate list's full
+    // sweeps stay on the grid)
+    {
+        int64_t per_pivot_arcs = 0;
+        if (opt.rule == MCF_RULE_DEVEX_BLOCK) {
+            int64_t bs = opt.block_size;
+            if (bs <= 0) bs = im.m < 1000 ? im.m / 4 : (im.m < 10000 ? im.m / 8 : im.m / 16);
+            per_pivot_arcs = bs < 1 ? 1 : bs;
+        } else if (opt.rule == MCF_RULE_DANTZIG_FULL) {
+            per_pivot_arcs = im.m;
+        }
+        const bool fits = im.n_nodes <= kMidMaxNodes && per_pivot_arcs <= kMidMaxArcsPerPivot;
+        h->mid = h->rcached && scan_ok && h->shards == 1 && !opt.profile && opt.mid_loop >= 0 && (fits || opt.mid_loop > 0);
     }
     const int rc = upload_image(h);
     if (rc != MCF_OK) { g_create_error = h->err; free_all(h); delete h; return rc; }
@@ -1096,8 +1257,13 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
     const int64_t start = h->h_ctx->pivots;
     const int64_t final_cap = start + max_pivots;
     if (cb_interval <= 0) cb_interval = 100;
-    const int batch = h->opt.batch_pivots;
-    const bool graph = h->opt.use_graph && !h->opt.profile && !h->small;
+    int batch = h->opt.batch_pivots;
+    if (h->mid) {  // a slot is a whole run of pivots there
+        const int per = h->opt.rule == MCF_RULE_CANDIDATE_LIST ? mcf_minor_cap(h->price_blocks) + 1 : batch;
+        batch = batch / per > 2 ? batch / per : 2;
+        if (h->opt.rule != MCF_RULE_CANDIDATE_LIST) batch = 1;
+    }
+    const bool graph = h->opt.use_graph && !h->opt.profile && !h->small && !(h->mid && batch == 1);
     if (graph) { rc = build_graph(h, batch); if (rc) return rc; }
     bool stop = false;
     while (!stop) {
@@ -1190,7 +1356,7 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
         h->stats.subtree_nodes = c.subtree_nodes; h->stats.cycle_arcs = c.cycle_arcs;
         h->stats.unbounded_arc = c.unbounded_arc >= 0 ? im.orig[c.unbounded_arc] : -1;
         h->stats.artificial_flow = r.artificial_flow;
-        h->stats.pricing_mode = h->small ? 2 : (h->rcached ? 1 : 0);
+        h->stats.pricing_mode = h->small ? 2 : (h->mid ? 3 : (h->rcached ? 1 : 0));
         h->stats.cycle_scans = c.scans; h->stats.scan_rounds = c.scan_rounds;
         h->stats.unbounded_rc = 0;
         if (c.status == MCF_UNBOUNDED && c.unbounded_arc >= 0) {

@@ -51,7 +51,7 @@ class McfOptions(ctypes.Structure):
         ("batch_pivots", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("profile", ctypes.c_int32),
         ("block_size", ctypes.c_int64), ("shard_rank", ctypes.c_int64), ("shard_count", ctypes.c_int64),
         ("price_blocks", ctypes.c_int32), ("no_fused", ctypes.c_int32), ("no_rcache", ctypes.c_int32),
-        ("cycle_scan", ctypes.c_int32),
+        ("cycle_scan", ctypes.c_int32), ("mid_loop", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -147,7 +147,7 @@ class McfEngine:
     def __init__(self, n: int, tail, head, cost, cap, supply, rule: int = RULE_DANTZIG, block_size: int = 0,
                  batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
                  shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
-                 resident_rc: bool = True, cycle_scan: int = 0):
+                 resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -176,6 +176,7 @@ class McfEngine:
         opt.no_fused = 0 if fused else 1
         opt.no_rcache = 0 if resident_rc else 1
         opt.cycle_scan = int(cycle_scan)
+        opt.mid_loop = int(mid_loop)
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule

@@ -71,6 +71,7 @@ void bind(Emul& e) {
     v.adj = nullptr;
     v.posbuf[0] = im.pos.data();
     v.posbuf[1] = e.pos1.data();
+    im.psize.resize((size_t)im.n_nodes + 4, 0);  // the scan reads whole groups of four positions
     e.psz1 = im.psize;
     v.psz[0] = im.psize.data();
     v.psz[1] = e.psz1.data();

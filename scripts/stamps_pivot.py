@@ -6,11 +6,13 @@ os.environ["MCF_HIP_LIB"] = str(ROOT / "scripts" / "libmcf_stamps.so")
 sys.path.insert(0, str(ROOT))
 import numpy as np
 from network_flow_solver_amd import engine, generators
-names = ["stage ctx+cand", "minor key + argmax", "accounting+begin", "cycle_init + barrier", "scan: setup", "scan: rounds", "scan: hit pass",
-         "scan: reduce+merge", "decide", "barrier+finish", "publish ctx"]
-for name, rule, cap in (("netgen_8_10a", 0, 10**9), ("netgen_8_14a", 0, 10**9), ("netgen_8_14a", 2, 10**9), ("goto_8_16a", 0, 60000)):
+MID = os.environ.get("MID", "0") == "1"
+names = ["stage ctx+cand" if not MID else "loop top", "minor key + argmax", "accounting+begin", "cycle_init + barrier", "scan: setup", "scan: rounds", "scan: hit pass",
+         "scan: reduce+merge", "decide", "barrier+finish", "publish ctx" if not MID else "update pass (apply+rcupd)"]
+CASES = (("netgen_8_10a", 1, 10**9), ("netgen_8_12a", 1, 10**9), ("netgen_8_14a", 1, 10**9), ("netgen_8_14a", 2, 10**9)) if MID else (("netgen_8_10a", 0, 10**9), ("netgen_8_14a", 0, 10**9), ("netgen_8_14a", 2, 10**9), ("goto_8_16a", 0, 60000))
+for name, rule, cap in CASES:
     inst = generators.named_instance(name)
-    eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
+    eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, mid_loop=1 if MID else -1)
     out = (ctypes.c_ulonglong * 24)()
     eng._lib.mcf_debug_pivot_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     eng._lib.mcf_debug_pivot_stamps(eng._h, out, 1)

@@ -81,7 +81,8 @@ def check_tree_invariants(n: int, parent, size, pos, order, depth=None, psize=No
         assert pos[p] < pos[v] and pos[v] + size[v] <= pos[p] + size[p], f"block of {v} not nested in {p}"
         child_sum[p] += size[v]
     assert np.array_equal(child_sum + 1, np.asarray(size, dtype=np.int64))
-    if psize is not None:  # position-space sizes: what the block-wide cycle scan tests ancestry with
+    if psize is not None and not (np.asarray(psize) == -1).all():  # position-space sizes: what the cycle scan tests
+        # ancestry with (-1 everywhere: the handle keeps none, e.g. the LDS-resident loop always climbs)
         assert np.array_equal(np.asarray(psize)[np.asarray(pos)], np.asarray(size))
     if depth is not None:  # the depth-balanced cycle walk relies on these
         assert depth[n] == 0 and all(depth[v] == depth[parent[v]] + 1 for v in range(n))

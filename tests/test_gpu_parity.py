@@ -57,8 +57,11 @@ def test_fused_lds_path_equals_three_kernel_path(gpu_engine_module, rule):
     for idx in (0, 3, 6):
         _, inst = load_synthetic()[idx]
         runs = [_solve(gpu_engine_module, inst, rule, fused=True),
-                _solve(gpu_engine_module, inst, rule, fused=False, use_graph=True),
-                _solve(gpu_engine_module, inst, rule, fused=False, use_graph=False, batch_pivots=7)]
+                _solve(gpu_engine_module, inst, rule, fused=False, mid_loop=-1, use_graph=True),
+                _solve(gpu_engine_module, inst, rule, fused=False, mid_loop=-1, use_graph=False, batch_pivots=7),
+                _solve(gpu_engine_module, inst, rule, fused=False, mid_loop=1),              # persistent loop, global state
+                _solve(gpu_engine_module, inst, rule, fused=False, mid_loop=1, use_graph=False)]
+        assert [r.stats["pricing_mode"] for r, _ in runs] == [2, 1, 1, 3, 3]
         (r0, t0) = runs[0]
         assert r0.stats["batches"] <= 2                      # one launch for the whole solve (+ re-arm)
         for r, t in runs[1:]:
@@ -68,14 +71,15 @@ def test_fused_lds_path_equals_three_kernel_path(gpu_engine_module, rule):
             assert r.stats["arcs_priced"] == r0.stats["arcs_priced"] and r.stats["degenerate"] == r0.stats["degenerate"]
 
 
+@pytest.mark.parametrize("mid_loop", [-1, 1], ids=["kernel_per_phase", "persistent_loop"])
 @pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
-def test_resident_reduced_costs_stay_exact(gpu_engine_module, rule):
+def test_resident_reduced_costs_stay_exact(gpu_engine_module, rule, mid_loop):
     """Large instances price from RESIDENT reduced costs that k_rcupd patches after every basis
     swap.  Invariant: the resident copy equals cost + pi[tail] - pi[head] for every arc, at every
     stage of the solve; and the pivot sequence equals the gather-priced one."""
     _, inst = load_synthetic()[7]                                  # 1 024 nodes / 8 192 arcs: past the LDS path
     e = gpu_engine_module
-    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule) as eng:
+    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, mid_loop=mid_loop) as eng:
         for budget in (0, 1, 5, 40, 300, 10 ** 9):
             if budget:
                 eng.solve(max_pivots=budget)
@@ -95,15 +99,15 @@ def test_resident_reduced_costs_stay_exact(gpu_engine_module, rule):
 
 
 @pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
-@pytest.mark.parametrize("idx,fused", [(3, True), (6, True), (6, False), (7, True)],
-                         ids=["netgen256_fused_lds", "goto256_fused_lds", "goto256_kernel_path", "netgen1024_kernel_path"])
-def test_cycle_scan_equals_cycle_climb(gpu_engine_module, idx, fused, rule):
+@pytest.mark.parametrize("idx", [3, 6, 7], ids=["netgen256", "goto256", "netgen1024"])
+def test_cycle_scan_equals_cycle_climb(gpu_engine_module, idx, rule):
     """The workgroup-wide scan over preorder positions (mcf_pivot_scan: ancestors found with the
     position-space subtree sizes, ratio test by team-wide atomics) against the one-lane parent-pointer
     climb: scan only, climb 3 then scan, climb only -- identical pivot sequence and tree, and identical
     to the CPU emulation."""
     _, inst = load_synthetic()[idx]
-    runs = {cs: _solve(gpu_engine_module, inst, rule, cycle_scan=cs, fused=fused) for cs in (-1, 1, 4)}
+    # (the LDS-resident loop always climbs: kernel-per-phase path here, the persistent loop has its own test)
+    runs = {cs: _solve(gpu_engine_module, inst, rule, cycle_scan=cs, fused=False, mid_loop=-1) for cs in (-1, 1, 4)}
     r0, t0 = runs[-1]
     assert r0.stats["cycle_scans"] == 0 and (t0["psize"] == -1).all()      # sizes are not even kept
     em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, climb_budget=0)
@@ -133,6 +137,34 @@ def test_cycle_scan_on_a_deep_tree(gpu_engine_module):
         assert np.array_equal(r.flow, a.flow) and np.array_equal(r.potential, a.potential)
         assert np.array_equal(t["order"], ta["order"]) and np.array_equal(t["depth"], ta["depth"])
         check_tree_invariants(inst.n, t["parent"], t["size"], t["pos"], t["order"], t["depth"], t["psize"])
+
+
+@pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
+@pytest.mark.parametrize("name", ["netgen_8_12a", "goto_8_12a"])
+def test_persistent_loop_equals_kernel_per_phase_path(gpu_engine_module, name, rule):
+    """k_solve_mid (one persistent workgroup does pricing of a block / re-pricing of the list, pivot, tree update
+    and reduced-cost update with the state in global memory) against the k_price_rc -> k_pivot -> k_update
+    launches: same pivots, same flows, same tree, resident reduced costs still exact; budgets and resumes land
+    on the same pivot counts."""
+    inst = generators.named_instance(name)
+    e = gpu_engine_module
+    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, mid_loop=1) as eng:
+        for budget in (1, 17, 1000):
+            eng.solve(max_pivots=budget)
+        assert eng.stats()["pivots"] == 1018 and eng.stats()["status"] == "iteration_limit"
+        eng.solve()
+        a, ta = eng.result(), eng.tree()
+        rc, resident = eng.reduced_costs()
+        assert resident and np.array_equal(rc, inst.cost + ta["pi"][inst.tail] - ta["pi"][inst.head])
+    b, tb = _solve(e, inst, rule, mid_loop=-1)
+    assert a.stats["pricing_mode"] == 3 and b.stats["pricing_mode"] == 1
+    assert a.status == b.status == "optimal" and a.objective == b.objective
+    assert a.stats["pivots"] == b.stats["pivots"] and a.stats["degenerate"] == b.stats["degenerate"]
+    assert a.stats["arcs_priced"] == b.stats["arcs_priced"]
+    assert np.array_equal(a.flow, b.flow) and np.array_equal(a.potential, b.potential)
+    for key in ("order", "parent", "size", "pos", "depth", "psize"):
+        assert np.array_equal(ta[key], tb[key]), key
+    check_optimality(inst, a.flow, a.potential)
 
 
 # ------------------------------------------------------------------ golden fixtures, through the reference-shaped API
