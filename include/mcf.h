@@ -149,6 +149,16 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
 /* Back to the all-artificial start basis (flows, potentials, tree, counters). */
 int mcf_reset(mcf_handle* h);
 
+/* Warm start (NetworkSimplex._apply_warm_start_basis, simplex.py:740-903, and _recompute_tree_flows,
+ * :905-1010): restart from the caller's basis instead of the all-artificial one.  in_tree[m] marks the basic
+ * arcs (they must form a forest; every component gets one artificial arc to the root, as in the reference);
+ * at_upper[m] (may be NULL) marks non-basic arcs sitting at their capacity rather than at zero (the reference
+ * keeps no such information in a Basis and starts them at zero).  Tree flows are recomputed from conservation
+ * with the handle's supplies / capacities.  Returns MCF_OK, or MCF_E_STATE when the basis cannot be used (cycle,
+ * empty, flows outside the bounds): the handle is then at the cold start and can be solved as usual -- the
+ * reference's fall-back (simplex.py:1527-1531).  Counters are reset either way. */
+int mcf_set_basis(mcf_handle* h, const int8_t* in_tree, const int8_t* at_upper);
+
 /* ---- arc-sharded multi-GPU pivoting: one handle per rank, every rank holds the full
  * replicated state and prices only its shard (options.shard_rank / shard_count).  Per pivot:
  *   mcf_enqueue_price   local best candidate -> cand_out (device, 2 x int64: key, packed arc id)

@@ -1232,7 +1232,21 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
 int mcf_reset(mcf_handle* h) {
     if (!h) return MCF_E_BAD_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
+    mcf_init_cold_basis(h->im);  // a warm start may have replaced the start basis in the host image
+    mcf_refresh_rcache(h->im);
     return upload_image(h);
+}
+
+int mcf_set_basis(mcf_handle* h, const int8_t* in_tree, const int8_t* at_upper) {
+    if (!h || !in_tree) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const std::string msg = mcf_apply_basis(h->im, in_tree, at_upper);
+    if (!msg.empty()) mcf_init_cold_basis(h->im);  // rejected: the image may be half written
+    mcf_refresh_rcache(h->im);
+    const int rc = upload_image(h);
+    if (rc) return rc;
+    if (!msg.empty()) { h->err = "warm-start basis rejected: " + msg; return MCF_E_STATE; }
+    return MCF_OK;
 }
 
 int mcf_set_max_pivots(mcf_handle* h, int64_t max_total_pivots) {

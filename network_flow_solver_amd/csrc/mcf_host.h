@@ -8,6 +8,7 @@
 //   _initialize_tree          :619-730  -> one artificial root arc per node, all basic
 //   basis.rebuild             basis.py:82-122 -> parent/pred/size/pos/order + potentials
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -39,6 +40,201 @@ struct McfHostImage {
     std::vector<int64_t> adj_off;           // [n + 1]
     std::vector<int64_t> adj;               // [2m]
 };
+
+// The all-artificial start basis (_initialize_tree, simplex.py:619-730): every real arc non-basic at its
+// lower bound, one artificial arc per node, all of them basic, carrying the node's supply to / from the root.
+inline void mcf_init_cold_basis(McfHostImage& im) {
+    const int32_t n = im.n, root = im.n;
+    const int64_t m = im.m;
+    for (int64_t e = 0; e < m; ++e) { im.state[e] = 1; im.arcw[e].flow = 0; }
+    std::fill(im.weight.begin(), im.weight.end(), 1.0f);
+    im.pi.assign(im.n_nodes, 0);
+    im.node.assign(im.n_nodes, McfNode{-1, -1, 1, 0});
+    im.order.assign(im.n_nodes, 0);
+    im.pos.assign(im.n_nodes, 0);
+    im.psize.assign(im.n_nodes, 1);
+    im.psize[0] = im.n_nodes;  // the root sits at position 0
+    im.node[root] = McfNode{-1, -1, im.n_nodes, 0};
+    im.order[0] = root;
+    im.pos[root] = 0;
+    for (int32_t v = 0; v < n; ++v) {
+        const int64_t a = m + v;
+        const int64_t s = im.supply[v];
+        // supply >= 0: arc v -> root carrying s (up arc); demand: root -> v carrying -s.
+        // Zero-flow tree arcs point at the root, so the start tree is strongly feasible.
+        const int32_t up = s >= 0 ? 1 : 0;
+        im.arcw[a] = McfArcW{MCF_INF, s >= 0 ? s : -s};
+        im.pi[v] = up ? -im.big_m : im.big_m;
+        im.node[v] = McfNode{root, (int32_t)((a << 1) | up), 1, 1};  // depth 1: hangs off the root
+        im.order[v + 1] = v;
+        im.pos[v] = v + 1;
+    }
+}
+
+// Warm start (simplex.py:740-1010 restated for the preorder-array tree): install the caller's basis.
+//   in_tree[m]   (caller's arc order) the basic real arcs; they must form a forest;
+//   at_upper[m]  (may be null) non-basic arcs that sit at their capacity instead of at zero.
+// Every component of the forest that does not reach the root gets one artificial arc (the reference adds
+// them per component, :826-873); tree flows follow from conservation (:905-1010) and must respect the
+// bounds, else the basis is rejected ("" = applied; on rejection the image is back at the cold start, so
+// the caller simply solves from there, as the reference does).  Beyond the reference: a basic arc that
+// sits at a bound pointing the wrong way (zero flow away from the root / full towards it) would break
+// the strongly feasible tree the pivot rule relies on; it is made non-basic at that bound and its
+// subtree re-hung on the root by a zero-flow artificial arc.
+inline std::string mcf_apply_basis(McfHostImage& im, const int8_t* in_tree, const int8_t* at_upper) {
+    const int32_t n = im.n, root = im.n, N = im.n_nodes;
+    const int64_t m = im.m;
+    if (!in_tree) return "null basis";
+    // --- forest check (union-find over the real nodes)
+    std::vector<int32_t> uf(N);
+    for (int32_t v = 0; v < N; ++v) uf[v] = v;
+    auto find = [&](int32_t x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
+    std::vector<int8_t> basic(m, 0);
+    int64_t nbasic = 0;
+    for (int64_t e = 0; e < m; ++e) {
+        if (!in_tree[im.orig[e]]) continue;
+        const int32_t a = find(im.tail[e]), b = find(im.head[e]);
+        if (a == b) return "basis arcs contain a cycle";
+        uf[a] = b;
+        basic[e] = 1;
+        ++nbasic;
+    }
+    if (nbasic == 0) return "empty basis";
+    // --- non-basic flows and node balances
+    std::vector<int64_t> flow(m, 0), bal(N, 0);
+    for (int32_t v = 0; v < n; ++v) bal[v] = im.supply[v];
+    for (int64_t e = 0; e < m; ++e) {
+        if (basic[e] || !at_upper || !at_upper[im.orig[e]]) continue;
+        const int64_t cp = im.arcw[e].cap;
+        if (cp >= MCF_INF) return "uncapacitated arc marked as sitting at its capacity";
+        flow[e] = cp;
+        bal[im.tail[e]] -= cp;
+        bal[im.head[e]] += cp;
+    }
+    // --- tree adjacency (CSR over the basic arcs)
+    std::vector<int64_t> off((size_t)N + 1, 0);
+    auto build_adj = [&](std::vector<int32_t>& adj) {
+        std::fill(off.begin(), off.end(), 0);
+        for (int64_t e = 0; e < m; ++e) if (basic[e]) { off[im.tail[e] + 1]++; off[im.head[e] + 1]++; }
+        for (int32_t v = 0; v < N; ++v) off[v + 1] += off[v];
+        adj.assign((size_t)off[N], 0);
+        std::vector<int64_t> fill(off.begin(), off.end() - 1);
+        for (int64_t e = 0; e < m; ++e) if (basic[e]) { adj[fill[im.tail[e]]++] = (int32_t)e; adj[fill[im.head[e]]++] = (int32_t)e; }
+    };
+    std::vector<int32_t> adj, order(N), parent(N), depth(N), stack;
+    std::vector<int64_t> parc(N);     // arc to the parent (>= m: artificial), -1 for the root
+    std::vector<int8_t> rep(N, 0);    // hangs on the root by its artificial arc
+    // preorder DFS from the root over: root -> every representative, basic arcs below
+    auto dfs = [&]() -> bool {
+        std::vector<int8_t> seen(N, 0);
+        int32_t cnt = 0;
+        order[cnt++] = root; seen[root] = 1; parent[root] = -1; parc[root] = -1; depth[root] = 0;
+        for (int32_t r = 0; r < n; ++r) {
+            if (!rep[r]) continue;
+            if (seen[r]) return false;
+            seen[r] = 1; parent[r] = root; parc[r] = m + r; depth[r] = 1;
+            stack.clear(); stack.push_back(r);
+            while (!stack.empty()) {
+                const int32_t u = stack.back(); stack.pop_back();
+                order[cnt++] = u;
+                for (int64_t p = off[u + 1] - 1; p >= off[u]; --p) {  // reversed push: children come out in adjacency order
+                    const int32_t e = adj[p];
+                    const int32_t w = im.tail[e] == u ? im.head[e] : im.tail[e];
+                    if (seen[w]) continue;
+                    seen[w] = 1; parent[w] = u; parc[w] = e; depth[w] = depth[u] + 1;
+                    stack.push_back(w);
+                }
+            }
+        }
+        return cnt == N;
+    };
+    // representatives: the lowest node of every component
+    {
+        std::vector<int8_t> have(N, 0);
+        for (int32_t v = 0; v < n; ++v) { const int32_t c = find(v); if (!have[c]) { have[c] = 1; rep[v] = 1; } }
+    }
+    build_adj(adj);
+    if (!dfs()) return "basis does not span the nodes";
+    // --- tree flows from conservation, children before parents; bounds checked
+    std::vector<int64_t> art_flow(n, 0);
+    std::vector<int8_t> art_up(n, 1);
+    auto flows_ok = [&]() -> bool {
+        std::vector<int64_t> b2(bal);
+        for (int32_t k = N - 1; k >= 1; --k) {
+            const int32_t v = order[k];
+            const int64_t a = parc[v];
+            const int64_t x = b2[v];  // surplus the subtree of v has to send up (negative: must receive)
+            if (a >= m) {
+                art_up[v] = x >= 0 ? 1 : 0;
+                art_flow[v] = x >= 0 ? x : -x;
+            } else {
+                const bool up = im.tail[a] == v;
+                const int64_t f = up ? x : -x;
+                if (f < 0 || f > im.arcw[a].cap) return false;
+                flow[a] = f;
+            }
+            b2[parent[v]] += x;
+        }
+        return b2[root] == 0;
+    };
+    if (!flows_ok()) return "basis incompatible with the current supplies / capacities";
+    // --- strong feasibility: drop wrong-way degenerate basic arcs, re-hang their subtrees on the root
+    bool changed = false;
+    for (int32_t k = 1; k < N; ++k) {
+        const int32_t v = order[k];
+        const int64_t a = parc[v];
+        if (a >= m) continue;
+        const bool up = im.tail[a] == v;
+        const int64_t cp = im.arcw[a].cap;
+        if ((up && cp < MCF_INF && flow[a] == cp) || (!up && flow[a] == 0)) {
+            basic[a] = 0;      // stays at the bound it is sitting on (its flow is unchanged, so are all balances)
+            rep[v] = 1;
+            changed = true;
+        }
+    }
+    if (changed) {
+        build_adj(adj);
+        // the dropped arcs' flows were tree flows so far: move them into the node balances
+        std::vector<int64_t> b3(N, 0);
+        for (int32_t v = 0; v < n; ++v) b3[v] = im.supply[v];
+        for (int64_t e = 0; e < m; ++e) if (!basic[e] && flow[e] != 0) { b3[im.tail[e]] -= flow[e]; b3[im.head[e]] += flow[e]; }
+        bal.swap(b3);
+        if (!dfs() || !flows_ok()) return "internal: strong-feasibility repair failed";
+    }
+    // --- install: states, flows, records, preorder arrays, potentials
+    for (int64_t e = 0; e < m; ++e) {
+        im.arcw[e].flow = flow[e];
+        const int64_t cp = im.arcw[e].cap;
+        im.state[e] = basic[e] ? 0 : ((flow[e] != 0 && flow[e] == cp) ? -1 : 1);
+    }
+    std::fill(im.weight.begin(), im.weight.end(), 1.0f);
+    for (int32_t v = 0; v < n; ++v) im.arcw[m + v] = McfArcW{MCF_INF, 0};
+    std::vector<int32_t> size(N, 1);
+    for (int32_t k = N - 1; k >= 1; --k) size[parent[order[k]]] += size[order[k]];
+    im.pi[root] = 0;
+    im.node[root] = McfNode{-1, -1, N, 0};
+    for (int32_t k = 0; k < N; ++k) {
+        const int32_t v = order[k];
+        im.order[k] = v;
+        im.pos[v] = k;
+        im.psize[k] = size[v];
+        if (v == root) continue;
+        const int64_t a = parc[v];
+        int32_t up;
+        int64_t c;
+        if (a >= m) { up = art_up[v]; c = im.big_m; im.arcw[a].flow = art_flow[v]; }
+        else { up = im.tail[a] == v ? 1 : 0; c = im.cost[a]; }
+        im.node[v] = McfNode{parent[v], (int32_t)((a << 1) | up), size[v], depth[v]};
+        im.pi[v] = up ? im.pi[parent[v]] - c : im.pi[parent[v]] + c;
+    }
+    return "";
+}
+
+// resident reduced costs of the current image (values only; the adjacency does not depend on the basis)
+inline void mcf_refresh_rcache(McfHostImage& im) {
+    if (im.rcache.empty()) return;
+    for (int64_t e = 0; e < im.m; ++e) im.rcache[e] = (int64_t)im.cost[e] + im.pi[im.tail[e]] - im.pi[im.head[e]];
+}
 
 // Validate the caller's arrays and build the start basis.  Returns "" or an error text.
 //
@@ -125,28 +321,7 @@ inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, co
     im.big_m = (max_abs_cost + 1) * ((int64_t)n + 2);
     if (im.big_m >= ((int64_t)1 << 44)) { *err_code = -5; return "max|cost| * n too large for the big-M start"; }
 
-    const int32_t root = n;
-    im.pi.assign(im.n_nodes, 0);
-    im.node.assign(im.n_nodes, McfNode{-1, -1, 1, 0});
-    im.order.assign(im.n_nodes, 0);
-    im.pos.assign(im.n_nodes, 0);
-    im.psize.assign(im.n_nodes, 1);
-    im.psize[0] = im.n_nodes;  // the root sits at position 0
-    im.node[root] = McfNode{-1, -1, im.n_nodes, 0};
-    im.order[0] = root;
-    im.pos[root] = 0;
-    for (int32_t v = 0; v < n; ++v) {
-        const int64_t a = m + v;
-        const int64_t s = supply[v];
-        // supply >= 0: arc v -> root carrying s (up arc); demand: root -> v carrying -s.
-        // Zero-flow tree arcs point at the root, so the start tree is strongly feasible.
-        const int32_t up = s >= 0 ? 1 : 0;
-        im.arcw[a] = McfArcW{MCF_INF, s >= 0 ? s : -s};
-        im.pi[v] = up ? -im.big_m : im.big_m;
-        im.node[v] = McfNode{root, (int32_t)((a << 1) | up), 1, 1};  // depth 1: hangs off the root
-        im.order[v + 1] = v;
-        im.pos[v] = v + 1;
-    }
+    mcf_init_cold_basis(im);
     *err_code = 0;
     return "";
 }

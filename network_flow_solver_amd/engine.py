@@ -27,7 +27,7 @@ CAP_INF = -1
 
 # every symbol include/mcf.h declares (tests check that the library exports each one)
 ABI_SYMBOLS = (
-    "mcf_default_options", "mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset",
+    "mcf_default_options", "mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis",
     "mcf_enqueue_price", "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing",
     "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_dimacs_scan", "mcf_dimacs_load", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
 )
@@ -98,6 +98,7 @@ def load_library():
     lib.mcf_get_result.argtypes = [vp, i32p, i64p, i64p, i64p, i8p, ctypes.POINTER(McfStats)]
     lib.mcf_price_once.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, i64p, i32p, i64p]
     lib.mcf_reset.argtypes = [vp]
+    lib.mcf_set_basis.argtypes = [vp, i8p, i8p]
     lib.mcf_enqueue_price.argtypes = [vp, vp, vp]
     lib.mcf_enqueue_pivot.argtypes = [vp, vp, vp, ctypes.c_int32]
     lib.mcf_poll.argtypes = [vp, vp, i32p, i64p]
@@ -113,7 +114,7 @@ def load_library():
     lib.mcf_last_error.restype = ctypes.c_char_p
     lib.mcf_destroy.argtypes = [vp]
     lib.mcf_destroy.restype = None
-    for name in ("mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_enqueue_price",
+    for name in ("mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis", "mcf_enqueue_price",
                  "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing", "mcf_time_copy",
                  "mcf_get_tree", "mcf_get_reduced_costs", "mcf_dimacs_scan", "mcf_dimacs_load"):
         getattr(lib, name).restype = ctypes.c_int
@@ -254,6 +255,24 @@ class McfEngine:
 
     def reset(self) -> None:
         self._check(self._lib.mcf_reset(self._h))
+
+    def set_basis(self, in_tree, at_upper=None) -> bool:
+        """Warm start from a basis (bool/int8 per arc, caller's order).  False when the engine rejected it
+        (cycle, empty, flows outside the bounds) -- the handle is then at the cold start, as in the reference."""
+        it = np.ascontiguousarray(in_tree, dtype=np.int8)
+        au = None if at_upper is None else np.ascontiguousarray(at_upper, dtype=np.int8)
+        if it.shape[0] != self.m or (au is not None and au.shape[0] != self.m):
+            raise ValueError("basis arrays must have one entry per arc")
+        if self.m == 0:
+            return False
+        rc = self._lib.mcf_set_basis(self._h, _p(it, ctypes.c_int8), None if au is None else _p(au, ctypes.c_int8))
+        if rc == -6:
+            return False
+        self._check(rc)
+        return True
+
+    def last_error(self) -> str:
+        return (self._lib.mcf_last_error(self._h) or b"").decode()
 
     def price_once(self, rule: int | None = None, start: int = 0, end: int | None = None):
         """One pricing pass. Returns (arc, dir, key) or None when no arc is eligible."""

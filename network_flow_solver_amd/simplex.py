@@ -163,6 +163,42 @@ class NetworkSimplex:
             return "dantzig"
         return self.options.pricing_strategy
 
+    def _apply_warm_start_basis(self, basis: Basis) -> bool:
+        """simplex.py:740-903: map the basis' (tail, head) keys onto arcs and hand them to the engine
+        (``mcf_set_basis``), which adds one artificial arc per uncovered component and recomputes the tree
+        flows from conservation (:905-1010).  False -> the engine is at the cold start (the reference's
+        fall-back).  ``Basis.arc_flows`` entries of arcs OUTSIDE ``tree_arcs`` (this build's results carry the
+        non-basic arcs that sit at capacity there; the reference ignores such keys) tell the engine which
+        non-basic arcs start at their upper bound."""
+        f = self.flat
+        if len(basis.tree_arcs) == 0:
+            self.logger.warning("Warm-start basis is empty. Falling back to cold start.")
+            return False
+        by_key: dict[tuple[str, str], list[int]] = {}
+        for i, key in enumerate(f.keys):
+            by_key.setdefault(key, []).append(i)
+        in_tree = np.zeros(len(f.keys), dtype=np.int8)
+        for key in basis.tree_arcs:
+            idxs = by_key.get(tuple(key))
+            if not idxs:
+                self.logger.warning(f"Warm-start basis contains arc {key} not in current problem. "
+                                    "Falling back to cold start.")
+                return False
+            in_tree[idxs[-1]] = 1                                  # like the reference's key -> index dict (:763-766)
+        at_upper = np.zeros(len(f.keys), dtype=np.int8)
+        for key, value in basis.arc_flows.items():
+            idxs = by_key.get(tuple(key))
+            if not idxs or tuple(key) in basis.tree_arcs:
+                continue
+            i = idxs[-1]
+            if f.cap[i] > 0 and round(float(value) * f.flow_scale) >= f.cap[i]:
+                at_upper[i] = 1
+        if self.engine.set_basis(in_tree, at_upper):
+            self.logger.info(f"Successfully applied warm-start basis with {int(in_tree.sum())} basis arcs")
+            return True
+        self.logger.warning(f"{self.engine.last_error()}. Falling back to cold start.")
+        return False
+
     def _objective_estimate(self, flow: np.ndarray) -> float:
         f = self.flat
         return float(np.dot(flow / f.flow_scale + f.lower, f.orig_cost))
@@ -177,7 +213,9 @@ class NetworkSimplex:
         if max_iterations is None:
             max_iterations = max(100, 20 * (m + n))               # simplex.py:1470 (len(arcs) incl. artificial)
         if warm_start_basis is not None:
-            self.logger.warning("warm_start_basis is not applied by the MI355X engine yet; cold start")
+            self.logger.info("Attempting to apply warm-start basis")      # simplex.py:1496
+            if not self._apply_warm_start_basis(warm_start_basis):
+                self.logger.info("Warm-start failed, performing cold start")  # simplex.py:1528
         start = time.time()
 
         progress = None
@@ -228,8 +266,13 @@ class NetworkSimplex:
             else:
                 flows[key] = float(round(value, 12))
         duals = {nid: float(round(int(res.potential[i]) / f.cost_scale, 12)) for i, nid in enumerate(f.node_ids)}
-        basis = Basis(                                            # simplex.py:1029-1039
-            tree_arcs={f.keys[i] for i in np.nonzero(res.in_tree)[0]},
-            arc_flows={f.keys[i]: float(res.flow[i]) / f.flow_scale for i in np.nonzero(res.in_tree)[0]})
+        # simplex.py:1029-1039 (tree arcs with their flows), plus -- outside tree_arcs, where the reference
+        # never looks -- the non-basic arcs sitting at capacity, so that a warm start can restore them
+        tree_idx = np.nonzero(res.in_tree)[0]
+        full_idx = np.nonzero(~res.in_tree & (f.cap > 0) & (res.flow == f.cap))[0]
+        arc_flows = {f.keys[i]: float(res.flow[i]) / f.flow_scale for i in tree_idx}
+        for i in full_idx:
+            arc_flows.setdefault(f.keys[i], float(res.flow[i]) / f.flow_scale)
+        basis = Basis(tree_arcs={f.keys[i] for i in tree_idx}, arc_flows=arc_flows)
         return FlowResult(objective=float(round(objective, 12)), flows=flows, status=res.status,
                           iterations=iterations, duals=duals, basis=basis)

@@ -291,14 +291,15 @@ def _load_emul():
         lib.emul_solve.argtypes = [
             ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, ctypes.c_int32, ctypes.c_int64,
             ctypes.c_int64, i32p, i64p, i64p, i64p, i8p, i64p, i32p, i32p, i32p, i32p, i32p, i64p, ctypes.c_int64,
-            ctypes.c_int32, i32p, i32p, ctypes.c_int32, i64p,
+            ctypes.c_int32, i32p, i32p, ctypes.c_int32, i64p, i8p, i8p, i32p,
         ]
         _emul = lib
     return _emul
 
 
 def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0, max_pivots: int = -1,
-               trace: int = 0, bucketed: bool = True, climb_budget: int = -1) -> dict:
+               trace: int = 0, bucketed: bool = True, climb_budget: int = -1,
+               warm_in_tree=None, warm_at_upper=None) -> dict:
     """Run the engine's integer pivot algorithm on the CPU. Arrays are 0-based ints; cap < 0 = inf.
     climb_budget < 0: the cycle is always found by pointer chasing; k >= 0: after k round trips the
     position-space scan (mcf_pivot_scan) takes over."""
@@ -318,6 +319,9 @@ def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int 
     parent, pred, size, pos, order, depth, psize = (np.zeros(n + 1, np.int32) for _ in range(7))
     tr = np.full(max(trace, 1), -2, np.int64)
     scan_stats = np.zeros(2, np.int64)
+    wt = None if warm_in_tree is None else np.ascontiguousarray(warm_in_tree, np.int8)
+    wu = None if warm_at_upper is None else np.ascontiguousarray(warm_at_upper, np.int8)
+    warm_applied = ctypes.c_int32(0)
     rc = lib.emul_solve(
         n, m, _ptr(tail, ctypes.c_int32), _ptr(head, ctypes.c_int32), _ptr(cost, ctypes.c_int64),
         _ptr(cap, ctypes.c_int64), _ptr(supply, ctypes.c_int64), rule, block_size, max_pivots,
@@ -325,7 +329,8 @@ def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int 
         _ptr(in_tree, ctypes.c_int8), _ptr(stats, ctypes.c_int64), _ptr(parent, ctypes.c_int32),
         _ptr(pred, ctypes.c_int32), _ptr(size, ctypes.c_int32), _ptr(pos, ctypes.c_int32),
         _ptr(order, ctypes.c_int32), _ptr(tr, ctypes.c_int64), trace, 1 if bucketed else 0, _ptr(depth, ctypes.c_int32),
-        _ptr(psize, ctypes.c_int32), climb_budget, _ptr(scan_stats, ctypes.c_int64))
+        _ptr(psize, ctypes.c_int32), climb_budget, _ptr(scan_stats, ctypes.c_int64),
+        None if wt is None else _ptr(wt, ctypes.c_int8), None if wu is None else _ptr(wu, ctypes.c_int8), ctypes.byref(warm_applied))
     if rc != 0:
         raise RuntimeError(f"emul_solve failed with code {rc}")
     objective = (int(obj[0]) << 64) + (int(obj[1]) & ((1 << 64) - 1))
@@ -334,7 +339,7 @@ def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int 
         "in_tree": in_tree[:m], "pivots": int(stats[0]), "degenerate": int(stats[1]), "bound_flips": int(stats[2]),
         "arcs_priced": int(stats[3]), "nodes_moved": int(stats[4]), "subtree_nodes": int(stats[5]),
         "cycle_arcs": int(stats[6]), "unbounded_arc": int(stats[7]), "artificial_flow": int(stats[8]),
-        "seconds": stats[9] / 1e9, "minor_pivots": int(stats[10]), "major_sweeps": int(stats[11]), "parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order, "depth": depth, "psize": psize, "scans": int(scan_stats[0]), "scan_rounds": int(scan_stats[1]),
+        "seconds": stats[9] / 1e9, "minor_pivots": int(stats[10]), "major_sweeps": int(stats[11]), "parent": parent, "pred_arc": pred, "size": size, "pos": pos, "order": order, "depth": depth, "psize": psize, "scans": int(scan_stats[0]), "scan_rounds": int(scan_stats[1]), "warm_applied": bool(warm_applied.value),
         "trace": tr[:trace] if trace else None,
     }
 

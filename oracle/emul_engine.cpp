@@ -150,12 +150,19 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
                int32_t* status, int64_t* objective_hi_lo, int64_t* flow, int64_t* potential, int8_t* in_tree,
                int64_t* stats /*[12]*/, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
                int32_t* order, int64_t* trace_arcs, int64_t trace_cap, int32_t bucketed, int32_t* depth, int32_t* psize,
-               int32_t climb_budget /* < 0: always climb */, int64_t* scan_stats /*[2] or null*/) {
+               int32_t climb_budget /* < 0: always climb */, int64_t* scan_stats /*[2] or null*/,
+               const int8_t* warm_in_tree /* null: cold start */, const int8_t* warm_at_upper, int32_t* warm_applied) {
     Emul e;
     e.rule = rule;
     int err = 0;
     std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e.im, &err, bucketed != 0);
     if (err) { std::fprintf(stderr, "emul_solve: %s\n", msg.c_str()); return err; }
+    if (warm_applied) *warm_applied = 0;
+    if (warm_in_tree) {  // same host routine the HIP library's mcf_set_basis runs
+        const std::string why = mcf_apply_basis(e.im, warm_in_tree, warm_at_upper);
+        if (!why.empty()) mcf_init_cold_basis(e.im);
+        else if (warm_applied) *warm_applied = 1;
+    }
     bind(e);
     McfCtx& c = e.ctx;
     c.max_pivots = max_pivots < 0 ? (20 * (m + n) > 100 ? 20 * (m + n) : 100) : max_pivots;

@@ -96,3 +96,63 @@ def test_cycle_scan_on_devex_and_candidate_list_rules():
                               climb_budget=0)
         assert np.array_equal(a["trace"], b["trace"]) and np.array_equal(a["flow"], b["flow"])
         assert b["objective"] == a["objective"] and b["scans"] > 0
+
+
+# ------------------------------------------------------------------ warm start (mcf_apply_basis, shared host code)
+def _basis_of(inst, res):
+    in_tree = np.asarray(res["in_tree"], dtype=np.int8)
+    at_upper = ((in_tree == 0) & (res["flow"] == inst.cap) & (inst.cap > 0)).astype(np.int8)
+    return in_tree, at_upper
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 5, 6, 7])
+def test_warm_start_from_the_optimal_basis_needs_almost_no_pivots(idx):
+    """simplex.py:740-1010: re-installing the final basis of a solve (tree arcs + which non-basic arcs sit at
+    capacity) reproduces the optimal flows by conservation; only wrong-way degenerate arcs the repair
+    step replaced by artificial ones may need a few degenerate pivots."""
+    _, inst = load_synthetic()[idx]
+    cold = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply)
+    it, au = _basis_of(inst, cold)
+    warm = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, warm_in_tree=it, warm_at_upper=au)
+    assert warm["warm_applied"] and warm["status"] == "optimal" and warm["objective"] == cold["objective"]
+    assert warm["pivots"] <= max(3, cold["pivots"] // 20)
+    assert warm["pivots"] == warm["degenerate"]  # the flow was already optimal
+    assert np.array_equal(warm["flow"], cold["flow"])
+    check_tree_invariants(inst.n, warm["parent"], warm["size"], warm["pos"], warm["order"], warm["depth"], warm["psize"])
+    check_optimality(inst, warm["flow"], warm["potential"])
+
+
+def test_warm_start_after_a_supply_change_reaches_the_cold_optimum():
+    _, inst = load_synthetic()[3]
+    cold0 = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply)
+    it, au = _basis_of(inst, cold0)
+    supply = inst.supply.copy()
+    src, dst = int(np.argmax(supply)), int(np.argmin(supply))
+    supply[src] += 7
+    supply[dst] -= 7
+    cold = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, supply)
+    warm = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, supply, warm_in_tree=it, warm_at_upper=au)
+    assert warm["status"] == cold["status"] == "optimal" and warm["objective"] == cold["objective"]
+    if warm["warm_applied"]:
+        assert warm["pivots"] < cold["pivots"]
+
+
+def test_warm_start_rejects_cycles_and_empty_bases_then_solves_cold():
+    _, inst = load_synthetic()[0]
+    cold = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply)
+    everything = np.ones(inst.m, np.int8)                          # 512 arcs on 64 nodes: cycles
+    r = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, warm_in_tree=everything)
+    assert not r["warm_applied"] and r["objective"] == cold["objective"] and r["pivots"] == cold["pivots"]
+    r = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, warm_in_tree=np.zeros(inst.m, np.int8))
+    assert not r["warm_applied"] and r["objective"] == cold["objective"]
+
+
+def test_warm_start_without_bound_information_still_reaches_the_optimum():
+    """What the reference's Basis carries: tree arcs only, non-basic arcs assumed at zero."""
+    for idx in (0, 3, 6):
+        _, inst = load_synthetic()[idx]
+        cold = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply)
+        it, _ = _basis_of(inst, cold)
+        r = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, warm_in_tree=it)
+        assert r["status"] == "optimal" and r["objective"] == cold["objective"]
+        check_optimality(inst, r["flow"], r["potential"])
