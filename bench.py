@@ -119,7 +119,8 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         out["kernel_ms"] = {"price": price_ms, "pivot": pivot_ms, "apply": apply_ms, "price_back_to_back": sweep_ms}
         mode = p1.get("pricing_mode", 0)
         kname = ("k_price_rc" if mode == 1 else "k_price") + ("<devex_block>" if rule == 1 else "<dantzig>")
-        out["pricing_mode"] = {0: "gather sweep", 1: "resident reduced costs", 2: "fused LDS loop"}.get(mode, str(mode))
+        out["pricing_mode"] = {0: "gather sweep", 1: "resident reduced costs", 2: "fused LDS loop",
+                               3: "persistent single-workgroup loop"}.get(mode, str(mode))
         traffic, traffic_src = None, None
         try:  # PMC traffic is collected offline (rocprofv3 --pmc passes) and committed under profiles/
             table = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())

@@ -694,10 +694,14 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycl
 // The whole cycle search + decision for single-threaded callers (CPU emulation): climb within the
 // budget, then -- when the view carries psz[] -- the scan as a team of one.
 MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
+    MCF_PSTAMP(12);
     if (!mcf_pivot_begin(v, best_key, best_arc, rule)) return;
+    MCF_PSTAMP(13);
     McfCycle cy;
     mcf_cycle_init(v, &cy);
+    MCF_PSTAMP(14);
     if (!mcf_pivot_climb(v, &cy, v.psz[0] ? v.ctx->climb_budget : INT32_MAX)) return;
+    MCF_PSTAMP(15);
     if (cy.u != cy.w) {
         McfScanAcc acc;
         mcf_scan_init(&acc);
@@ -705,6 +709,7 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
         if (v.ctx->status != MCF_RUNNING) return;
     }
     mcf_pivot_decide(v, mcf_view_paths(v), cy);
+    MCF_PSTAMP(16);
 }
 
 MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane, int32_t nlanes) {

@@ -579,6 +579,65 @@ __global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
         if (j < c.lo || j >= c.hi) mcf_apply_one(v, c, (int32_t)j);
 }
 
+// ------------------------------------------------------------------ two-lane cycle climb (LDS loop)
+// With the tree in LDS the climb is bound by instruction issue of ONE lane (~150 instructions per round trip for
+// the two sides), not by latency.  Lanes 0 and 1 of a wave therefore climb one side each in lock step -- the same
+// instruction stream serves both sides -- and swap (node, depth) with one DPP move per word and round trip.  The
+// steps, the recorded paths and the ratio-test winners are exactly those of mcf_pivot_climb (depth-balanced: a side
+// moves when it is at least as deep as the other); lane 0 gets the finished McfCycle.  Called by lanes 0 and 1 only.
+__device__ __forceinline__ int swap01(int x) { return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
+
+__device__ __forceinline__ bool pivot_climb_2lanes(const McfView& v, McfCycle* out) {
+    const McfCtx* c = v.ctx;
+    const int side = threadIdx.x & 1;  // 0: first side, 1: second side
+    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
+    int32_t node = side ? c->pv_second : c->pv_first;
+    McfNode rec = v.node[node];
+    int32_t pos = pcur[node];
+    const McfNode rec0 = rec;
+    const int32_t pos0 = pos;
+    int32_t* const path = side ? v.path2 : v.path1;
+    int32_t* const ppos = side ? v.ppos2 : v.ppos1;
+    McfNode* const recs = side ? v.rec2 : v.rec1;
+    int64_t d = MCF_INF;
+    int32_t k = -1, n = 0, trips = 0;
+    bool ok = true;
+    for (;;) {
+        const int32_t onode = swap01(node), odepth = swap01(rec.depth);
+        if (node == onode) break;
+        if (rec.depth >= odepth) {
+            const McfNode nrec = v.node[rec.parent];
+            const int32_t npos = pcur[rec.parent];
+            const McfArcW a = v.arcw[rec.pred >> 1];
+            // first side is walked against the flow (an up arc loses flow), second side with it
+            const bool loses = ((rec.pred & 1) != 0) != (side != 0);
+            const int64_t r = loses ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
+            if (side ? r <= d : r < d) { d = r; k = n; }
+            path[n] = node;
+            recs[n] = rec;
+            ppos[n] = pos;
+            ++n;
+            node = rec.parent;
+            rec = nrec;
+            pos = npos;
+        }
+        if (++trips > v.n_nodes) { ok = false; break; }  // depths out of sync: never spin (both lanes count alike)
+    }
+    // hand the second side to lane 0
+    const int32_t od_lo = swap01((int)(uint32_t)d), od_hi = swap01((int)(uint32_t)((uint64_t)d >> 32));
+    const int32_t ok2 = swap01(k), on2 = swap01(n), opos0 = swap01(pos0);
+    McfNode orec0;
+    orec0.parent = swap01(rec0.parent); orec0.pred = swap01(rec0.pred); orec0.size = swap01(rec0.size); orec0.depth = swap01(rec0.depth);
+    if (side == 0) {
+        out->d1 = d; out->k1 = k; out->n1 = n;
+        out->d2 = (int64_t)(((uint64_t)(uint32_t)od_hi << 32) | (uint32_t)od_lo); out->k2 = ok2; out->n2 = on2;
+        out->u = node; out->w = node; out->pu = pos; out->pw = pos; out->ru = rec; out->rw = rec;
+        out->p0u = pos0; out->p0w = opos0; out->r0u = rec0; out->r0w = orec0;
+        out->small = 0;
+    }
+    return ok;
+}
+
 // ------------------------------------------------------------------ k_solve_small: fused LDS-resident pivot loop
 // Instances whose whole state fits in one CU's 160 KiB of LDS (netgen_8_08a: ~96 KiB) are
 // latency-bound, not bandwidth-bound: 27 KB per sweep is nothing, three kernel boundaries and
@@ -619,6 +678,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
 #ifdef MCF_STAMPS
     unsigned long long stamps_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = last_; }
 #endif
     const uint32_t m_pad4 = (uint32_t)((g.m + 1023) / 1024 * 1024) * 4u;
     const uint32_t m_padb = m_pad4 >> 2;
@@ -750,10 +810,26 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
                 for (int x = 0; x < MCF_NUM_BUCKETS; ++x) priced += s_hi[row + x] - s_lo[row + x];
                 c->arcs_priced += minor ? MCF_NUM_BUCKETS : priced;
             }
-            // With the tree in LDS a climb step costs ~100 cycles: the one-lane walk (its state in registers) beats
-            // the workgroup-wide scan and its barriers (measured 130 K vs 116 K pivots/s on netgen_8_08a), so the
-            // LDS loop keeps no position-space sizes at all.
-            mcf_pivot_walk(v, key, arc, rule);
+        }
+        // With the tree in LDS a climb step costs ~100 cycles of latency: walking beats the workgroup-wide scan and
+        // its barriers (measured 130 K vs 116 K pivots/s on netgen_8_08a), so the LDS loop keeps no position-space
+        // sizes at all.  Lanes 0 and 1 climb one side each (pivot_climb_2lanes), lane 0 does the rest.
+        if (threadIdx.x < 2) {
+            MCF_PSTAMP(12);
+            int go = 0;
+            if (threadIdx.x == 0) go = mcf_pivot_begin(v, key, arc, rule) ? 1 : 0;
+            go = __builtin_amdgcn_readfirstlane(go);
+            MCF_PSTAMP(13);
+            if (go) {
+                McfCycle cy;
+                const bool ok = pivot_climb_2lanes(v, &cy);
+                MCF_PSTAMP(15);
+                if (threadIdx.x == 0) {
+                    if (ok) mcf_pivot_decide(v, mcf_view_paths(v), cy);
+                    else c->status = MCF_INTERNAL_ERROR;
+                }
+                MCF_PSTAMP(16);
+            }
         }
         STAMP(3);
         __syncthreads();
@@ -793,6 +869,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     if (threadIdx.x == 0) {  // diagnostic build only: cycle sums into the (global) path scratch, read by mcf_debug_stamps
         unsigned long long* out = reinterpret_cast<unsigned long long*>(g.rec1);
         for (int i = 0; i < 8; ++i) out[i] = stamps_[i];
+        for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i];
     }
 #endif
 }

@@ -171,7 +171,8 @@ class McfEngine:
         opt.rule = rule
         opt.block_size = int(block_size or 0)
         opt.batch_pivots = int(batch_pivots)
-        opt.use_graph = 1 if use_graph else 0
+        # MCF_USE_GRAPH=0: eager launches (rocprofv3 on this image faults inside hipGraphLaunch for some graphs)
+        opt.use_graph = 1 if use_graph and os.environ.get("MCF_USE_GRAPH", "1") != "0" else 0
         opt.profile = 1 if profile else 0
         opt.price_blocks = int(price_blocks)
         opt.no_fused = 0 if fused else 1

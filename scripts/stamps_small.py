@@ -20,4 +20,10 @@ for rule in (0, 1):
     print("rule", rule, "pivots", piv, "solve_s", st["solve_seconds"], "ticks/pivot in loop", v[1:6].sum() / piv)
     for n, x in zip(names, v):
         print(f"   {n:9s} {x:14.0f}  per pivot {x / piv:9.1f}  share {100 * x / v.sum():5.1f}%")
+    out2 = (ctypes.c_ulonglong * 24)()
+    eng._lib.mcf_debug_pivot_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    eng._lib.mcf_debug_pivot_stamps(eng._h, out2, 1)
+    w = np.array(list(out2), dtype=np.float64)
+    for n, x in zip(["(to walk start)", "begin", "cycle_init", "climb", "decide"], w[12:17]):
+        print(f"      walk/{n:16s} per pivot {x / piv:9.1f}")
     eng.close()
