@@ -70,6 +70,31 @@ enum McfStatus : int32_t {
 #define MCF_RULE_CANDIDATE_LIST 2
 #endif
 
+#if defined(__HIPCC__)
+// Wave-wide max of a signed 64-bit value with DPP moves (row-local butterflies, then the two row broadcasts of
+// gfx9) instead of ds_bpermute shuffles: ~6 x (2 dpp movs + a 64-bit compare/select) of a few cycles each, versus
+// twelve dependent trips through the LDS crossbar.  All 64 lanes of the wave must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int64_t mcf_dpp_max_step(int64_t x) {
+    const int lo = (int)(uint32_t)x, hi = (int)(uint32_t)((uint64_t)x >> 32);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const int64_t o = (int64_t)(((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo);
+    return o > x ? o : x;
+}
+__device__ __forceinline__ int64_t mcf_wave_max64(int64_t x) {
+    x = mcf_dpp_max_step<0xB1, 0xf>(x);   // quad_perm [1,0,3,2]
+    x = mcf_dpp_max_step<0x4E, 0xf>(x);   // quad_perm [2,3,0,1]
+    x = mcf_dpp_max_step<0x141, 0xf>(x);  // row_half_mirror
+    x = mcf_dpp_max_step<0x140, 0xf>(x);  // row_mirror: every lane of a row of 16 now holds the row's max
+    x = mcf_dpp_max_step<0x142, 0xa>(x);  // row_bcast15 into rows 1 and 3
+    x = mcf_dpp_max_step<0x143, 0xc>(x);  // row_bcast31 into rows 2 and 3: lane 63 holds the max of the wave
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), 63);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+#endif
+
 // Diagnostic build (-DMCF_STAMPS): cycle stamps of the one-workgroup pivot kernel, accumulated per phase.
 #if defined(MCF_STAMPS) && defined(__HIPCC__)
 __shared__ unsigned long long mcf_stamp_acc[24];
@@ -271,8 +296,16 @@ struct McfPaths {
     int32_t *path1, *path2;
     McfNode *rec1, *rec2;
     int32_t *ppos1, *ppos2;
+    int64_t *flow1, *flow2;  // the arcs' flows as read by the hit pass, or null (then the finish pass re-reads them)
 };
-MCF_HD McfPaths mcf_view_paths(const McfView& v) { return McfPaths{v.path1, v.path2, v.rec1, v.rec2, v.ppos1, v.ppos2}; }
+MCF_HD McfPaths mcf_view_paths(const McfView& v) {
+    return McfPaths{v.path1, v.path2, v.rec1, v.rec2, v.ppos1, v.ppos2, nullptr, nullptr};
+}
+
+// One-sided ancestor noted by the scan rounds: (preorder position << 1) | side.  (Fetching the node record right
+// in the round was measured and lost: the wave that finds a hit stalls on two dependent loads per hit while the
+// other waves wait for it at the round's barrier -- rounds 5.3 K -> 11.1 K ticks on netgen_8_14a.)
+typedef int32_t McfHit;
 
 // State of the cycle search, shared by the climb (one lane) and the scan (the whole team).
 struct McfCycle {
@@ -458,31 +491,33 @@ MCF_HD void mcf_scan_init(McfScanAcc* acc) {
     acc->nhits = 0;
 }
 
-// The dense pass over the hit list: node id, record, tree arc of every one-sided ancestor -> its slot in
-// the path buffers `pb`, and this lane's best residual per side.
-MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_t* ord, const int32_t* hits,
-                              int32_t hits_cap, const int32_t* spill, int32_t nhits, int32_t base1, int32_t base2,
-                              int32_t du, int32_t dw, int32_t lane, int32_t nlanes, McfScanBest* out) {
+// The dense pass over the hit list: node id, record, tree arc of every one-sided ancestor (three dependent loads
+// for the whole cycle) -> its slot in the path buffers `pb`, and this lane's best residual per side.
+MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_t* ord, const McfHit* hits, int32_t hits_cap,
+                              const McfHit* spill, int32_t nhits, int32_t base1, int32_t base2, int32_t du, int32_t dw,
+                              int32_t lane, int32_t nlanes, McfScanBest* out) {
     int64_t b1r = 0, b2r = 0;
     int32_t b1i = -1, b2i = -1;
     for (int32_t t = lane; t < nhits; t += nlanes) {
-        int32_t hrec;
-        if (t < hits_cap) hrec = hits[t]; else hrec = spill[t - hits_cap];
-        const int32_t nd = ord[hrec >> 1];
-        const McfNode rec = v.node[nd];
+        int32_t pos_side;
+        if (t < hits_cap) pos_side = hits[t]; else pos_side = spill[t - hits_cap];
+        const int32_t node = ord[pos_side >> 1];
+        const McfNode rec = v.node[node];
         const McfArcW a = v.arcw[rec.pred >> 1];
-        if (!(hrec & 1)) {
+        if (!(pos_side & 1)) {
             const int32_t idx = base1 + du - rec.depth;
-            pb.path1[idx] = nd;
+            pb.path1[idx] = node;
             pb.rec1[idx] = rec;
-            pb.ppos1[idx] = hrec >> 1;
+            pb.ppos1[idx] = pos_side >> 1;
+            if (pb.flow1) pb.flow1[idx] = a.flow;
             const int64_t r = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
             if (b1i < 0 || r < b1r || (r == b1r && idx < b1i)) { b1r = r; b1i = idx; }
         } else {
             const int32_t idx = base2 + dw - rec.depth;
-            pb.path2[idx] = nd;
+            pb.path2[idx] = node;
             pb.rec2[idx] = rec;
-            pb.ppos2[idx] = hrec >> 1;
+            pb.ppos2[idx] = pos_side >> 1;
+            if (pb.flow2) pb.flow2[idx] = a.flow;
             const int64_t r = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
             if (b2i < 0 || r < b2r || (r == b2r && idx > b2i)) { b2r = r; b2i = idx; }
         }
@@ -495,12 +530,13 @@ MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_
 // scan alone that fits is recorded there (cy->small = 1), which spares the decide / finish passes a
 // global round trip per look-up.  The caller has run mcf_scan_init(acc) before the barrier in front of this call.
 MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_cap, McfCycle* cy, McfScanAcc* acc,
-                           int32_t* hits, int32_t hits_cap, int32_t lane, int32_t nlanes) {
+                           McfHit* hits, int32_t hits_cap, int32_t lane, int32_t nlanes) {
     McfCtx* c = v.ctx;
     const int32_t* ord = c->cur ? v.order[1] : v.order[0];
     const int32_t* psz = c->cur ? v.psz[1] : v.psz[0];
-    int32_t* spill = reinterpret_cast<int32_t*>(v.seg);  // scratch the finish pass only fills later; <= n_nodes entries
+    McfHit* spill = reinterpret_cast<McfHit*>(v.seg);  // scratch the finish pass only fills later; <= n_nodes entries
     const int32_t pu = cy->pu, pw = cy->pw, du = cy->ru.depth, dw = cy->rw.depth;
+    const int32_t pmin = pu < pw ? pu : pw;
     const int32_t base1 = cy->n1, base2 = cy->n2;
     MCF_PSTAMP(4);
     // groups of four positions, aligned; psz[] is padded so that the group holding max(pu, pw) can be read whole
@@ -533,24 +569,21 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
             const int32_t slice = lo + k * nlanes * 4;
             if (slice + nlanes * 4 <= 0) continue;
             const int32_t i0 = slice + lane * 4;
-            // i <= p < i + size  <=>  unsigned(p - i) < unsigned(size)   (sizes are positive; 0 marks "no position").
-            // Branch-free test of the four positions first: ancestors are rare.
-            uint32_t mu = 0, mw = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
+            // Cheap reject of the whole group first: a subtree can hold pu or pw only if it reaches past the lower
+            // of the two, and almost every position is a small subtree far to the left of both.
+            int32_t zmax = sz[k][0] > sz[k][1] ? sz[k][0] : sz[k][1];
+            const int32_t z23 = sz[k][2] > sz[k][3] ? sz[k][2] : sz[k][3];
+            zmax = zmax > z23 ? zmax : z23;
+            if (i0 + 3 + zmax <= pmin) continue;
             for (int e = 0; e < 4; ++e) {
-                mu |= (uint32_t)((uint32_t)(pu - i0 - e) < (uint32_t)sz[k][e]) << e;
-                mw |= (uint32_t)((uint32_t)(pw - i0 - e) < (uint32_t)sz[k][e]) << e;
-            }
-            if (!(mu | mw)) continue;
-            for (int e = 0; e < 4; ++e) {
-                const bool au = (mu >> e) & 1, aw = (mw >> e) & 1;
                 const int32_t i = i0 + e;
+                // i <= p < i + size  <=>  unsigned(p - i) < unsigned(size)   (sizes are positive; 0 marks "no position")
+                const bool au = (uint32_t)(pu - i) < (uint32_t)sz[k][e];
+                const bool aw = (uint32_t)(pw - i) < (uint32_t)sz[k][e];
                 if (au && aw) MCF_ATOMIC_MAX32(&acc->jpos[par], i);
                 else if (au || aw) {
                     const int32_t slot = MCF_ATOMIC_ADD32(&acc->nhits, 1);
-                    const int32_t hrec = (i << 1) | (aw ? 1 : 0);
+                    const McfHit hrec = (i << 1) | (aw ? 1 : 0);
                     if (slot < hits_cap) hits[slot] = hrec; else spill[slot - hits_cap] = hrec;
                 }
             }
@@ -582,16 +615,19 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
     else mcf_scan_hit_pass(v, mcf_view_paths(v), ord, hits, hits_cap, spill, nhits, base1, base2, du, dw, lane, nlanes, &best);
     MCF_PSTAMP(6);
 #if defined(__HIP_DEVICE_COMPILE__)
-    // hit t was handled by lane t % nlanes: waves beyond ceil(nhits / 64) hold nothing
+    // hit t was handled by lane t % nlanes: waves beyond ceil(nhits / 64) hold nothing.  Per side two DPP max
+    // reductions: the smallest residual, then the wanted path index among the lanes that hold it.
     const int32_t wave = lane >> 6, nwaves_hit = nhits >= nlanes ? nlanes >> 6 : (nhits + 63) >> 6;
     if (wave < nwaves_hit) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const int64_t r1 = (int64_t)__shfl_xor((long long)best.b1r, off, 64), r2 = (int64_t)__shfl_xor((long long)best.b2r, off, 64);
-            const int32_t i1 = __shfl_xor(best.b1i, off, 64), i2 = __shfl_xor(best.b2i, off, 64);
-            mcf_scan_best_merge(&best, r1, i1, r2, i2);
+        const int64_t kNone = INT64_MIN;
+        const int64_t m1 = mcf_wave_max64(best.b1i >= 0 ? -best.b1r : kNone);
+        const int64_t x1 = mcf_wave_max64(best.b1i >= 0 && -best.b1r == m1 ? -(int64_t)best.b1i : kNone);  // lowest index
+        const int64_t m2 = mcf_wave_max64(best.b2i >= 0 ? -best.b2r : kNone);
+        const int64_t x2 = mcf_wave_max64(best.b2i >= 0 && -best.b2r == m2 ? (int64_t)best.b2i : kNone);   // highest index
+        if ((lane & 63) == 0) {
+            acc->wr1[wave] = m1 == kNone ? 0 : -m1; acc->wi1[wave] = m1 == kNone ? -1 : (int32_t)(-x1);
+            acc->wr2[wave] = m2 == kNone ? 0 : -m2; acc->wi2[wave] = m2 == kNone ? -1 : (int32_t)x2;
         }
-        if ((lane & 63) == 0) { acc->wr1[wave] = best.b1r; acc->wr2[wave] = best.b2r; acc->wi1[wave] = best.b1i; acc->wi2[wave] = best.b2i; }
     }
     MCF_TEAM_BARRIER();
     if (lane == 0) {
@@ -705,7 +741,7 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     if (cy.u != cy.w) {
         McfScanAcc acc;
         mcf_scan_init(&acc);
-        mcf_pivot_scan(v, mcf_view_paths(v), 0, &cy, &acc, nullptr, 0, 0, 1);
+        mcf_pivot_scan(v, mcf_view_paths(v), 0, &cy, &acc, nullptr, 0, 0, 1);  // hit list: the scratch behind v.seg
         if (v.ctx->status != MCF_RUNNING) return;
     }
     mcf_pivot_decide(v, mcf_view_paths(v), cy);
@@ -726,7 +762,9 @@ MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane,
             const int32_t p = side1 ? pp.rec1[i].pred : pp.rec2[i - n1].pred;
             const bool up = (p & 1) != 0;
             // first side is walked against the flow, second side with it
-            v.arcw[p >> 1].flow += (side1 == up) ? -delta : delta;
+            const int64_t dlt = (side1 == up) ? -delta : delta;
+            if (pp.flow1) v.arcw[p >> 1].flow = (side1 ? pp.flow1[i] : pp.flow2[i - n1]) + dlt;  // read by the hit pass already
+            else v.arcw[p >> 1].flow += dlt;
         }
         if (lane == 0) v.arcw[e].flow += (int64_t)s * delta;
     }

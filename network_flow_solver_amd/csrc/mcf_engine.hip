@@ -64,30 +64,8 @@ __device__ __forceinline__ int64_t readlane64(int64_t x, int lane) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-// Wave-wide max of a signed 64-bit value with DPP moves (row-local butterflies, then the two row
-// broadcasts of gfx9) instead of ds_bpermute shuffles: ~6 x (2 dpp movs + a 64-bit compare/select) of a
-// few cycles each, versus twelve dependent trips through the LDS crossbar.  All 64 lanes must be active.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int64_t dpp_max_step(int64_t x) {
-    const int lo = (int)(uint32_t)x, hi = (int)(uint32_t)((uint64_t)x >> 32);
-    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    const int64_t o = (int64_t)(((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo);
-    return o > x ? o : x;
-}
-
-__device__ __forceinline__ int64_t wave_max64(int64_t x) {
-    x = dpp_max_step<0xB1, 0xf>(x);   // quad_perm [1,0,3,2]
-    x = dpp_max_step<0x4E, 0xf>(x);   // quad_perm [2,3,0,1]
-    x = dpp_max_step<0x141, 0xf>(x);  // row_half_mirror
-    x = dpp_max_step<0x140, 0xf>(x);  // row_mirror: every lane of a row of 16 now holds the row's max
-    x = dpp_max_step<0x142, 0xa>(x);  // row_bcast15 into rows 1 and 3
-    x = dpp_max_step<0x143, 0xc>(x);  // row_bcast31 into rows 2 and 3: lane 63 holds the max of the wave
-    return readlane64(x, 63);
-}
-
 __device__ __forceinline__ void wave_argmax(int64_t& key, int64_t& arc) {
-    const int64_t mx = wave_max64(key);
+    const int64_t mx = mcf_wave_max64(key);  // DPP reduction (mcf_core.h)
     uint64_t mask = __ballot(key == mx && key > 0);
     int64_t best = -1;
     while (mask) {  // uniform loop: one iteration unless several lanes tie on the key
@@ -353,7 +331,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce(const McfCand* __rest
 #ifdef MCF_STAMPS
 __device__ unsigned long long g_pivot_stamps[24];
 #endif
-constexpr int kHitsLds = 4096;   // hit-list entries kept in LDS (a longer cycle spills to global scratch)
+constexpr int kHitsLds = 4096;  // hit-list entries kept in LDS (a longer cycle spills to global scratch)
 constexpr int kSmallPath = 512;  // cycles up to this many nodes are recorded in LDS instead of the global path scratch
 
 // LDS state of one pivoting workgroup (k_pivot, k_solve_mid)
@@ -362,9 +340,10 @@ struct PivotShared {
     McfCycle cy;
     McfScanAcc acc;
     int go;  // 0 = nothing to pivot on, 1 = the climb reached the join, 2 = the scan has to finish the cycle
-    int32_t hits[kHitsLds];
+    McfHit hits[kHitsLds];
     int32_t path[2][kSmallPath], ppos[2][kSmallPath];
     McfNode rec[2][kSmallPath];
+    int64_t flow[2][kSmallPath];
 };
 constexpr int kCtxWords = (int)(sizeof(McfCtx) / 4);
 static_assert(sizeof(McfCtx) % 4 == 0 && kCtxWords <= kPivotThreads, "control block staging");
@@ -390,7 +369,7 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
     MCF_PSTAMP(3);
     const int go = S.go;
     const McfPaths gp = mcf_view_paths(v);                                                    // cycle scratch in global memory
-    const McfPaths sp = McfPaths{S.path[0], S.path[1], S.rec[0], S.rec[1], S.ppos[0], S.ppos[1]};  // ... and in LDS
+    const McfPaths sp = McfPaths{S.path[0], S.path[1], S.rec[0], S.rec[1], S.ppos[0], S.ppos[1], S.flow[0], S.flow[1]};  // ... and in LDS
     if (go == 2) mcf_pivot_scan(v, sp, kSmallPath, &S.cy, &S.acc, S.hits, kHitsLds, threadIdx.x, kPivotThreads);  // barriers inside
     // S.cy.small is written by lane 0 at the very end of the scan: lane 0 may use it at once, the others after the barrier.
     // Separate calls for the two scratch locations: each inlined copy works on one known address space.
