@@ -1350,9 +1350,14 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
             if (h->small)
                 hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(kSmallThreads), h->small_layout.total, h->stream, h->view,
                                    h->small_layout, h->opt.rule, h->d_cand);
-            else if (h->opt.profile) { rc = run_batch_profiled(h, batch); if (rc) return rc; }
-            else if (graph) HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
-            else for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream, i);
+            else {
+                // eager launches need not run past the cap (a replayed graph has a fixed length: its surplus slots early-exit)
+                const int64_t left = cap - h->h_ctx->pivots;
+                const int slots = h->mid ? batch : (int)(left < 1 ? 1 : (left < batch ? left : batch));
+                if (h->opt.profile) { rc = run_batch_profiled(h, slots); if (rc) return rc; }
+                else if (graph) HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
+                else for (int i = 0; i < slots; ++i) launch_pivot_triplet(h, h->stream, i);
+            }
             HIP_TRY(h, hipGetLastError());
             rc = read_ctx(h, h->stream);
             if (rc) return rc;
