@@ -167,6 +167,39 @@ def test_persistent_loop_equals_kernel_per_phase_path(gpu_engine_module, name, r
     check_optimality(inst, a.flow, a.potential)
 
 
+def _chain_instance(n, skip=7):
+    """A path 0 -> 1 -> ... -> n-1 with capacity 10, shortcut arcs every `skip` nodes and one expensive direct
+    arc; 15 units from 0 to n-1.  The optimal tree is essentially the path: cycles thousands of arcs long (the
+    reference's long-chain graphs, tests/test_large_directed.py:14-128, scaled up)."""
+    tail = list(range(n - 1)) + list(range(0, n - skip, skip)) + [0]
+    head = list(range(1, n)) + list(range(skip, n, skip))[: len(range(0, n - skip, skip))] + [n - 1]
+    m1, m2 = n - 1, len(range(0, n - skip, skip))
+    cost = [1] * m1 + [skip + 2] * m2 + [3 * n]
+    cap = [10] * m1 + [4] * m2 + [100]
+    supply = np.zeros(n, np.int64)
+    supply[0], supply[n - 1] = 15, -15
+    return generators.ArcSoA(n=n, tail=np.array(tail, np.int32), head=np.array(head, np.int32), cost=np.array(cost, np.int64),
+                             cap=np.array(cap, np.int64), supply=supply, name=f"chain_{n}")
+
+
+@pytest.mark.parametrize("mid_loop", [-1, 1], ids=["kernel_per_phase", "persistent_loop"])
+def test_cycle_scan_with_cycles_longer_than_the_lds_buffers(gpu_engine_module, mid_loop):
+    """12 000-node chain: cycles of ~6 000 arcs overflow the LDS hit list (4 096 entries) and the LDS path
+    buffers (512), so the spill list and the global path scratch are exercised; several scan rounds per pivot.
+    Pivot for pivot against the CPU emulation."""
+    inst = _chain_instance(12000)
+    em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0, climb_budget=0)
+    assert em["status"] == "optimal" and em["cycle_arcs"] / em["pivots"] > 4096
+    res, tree = _solve(gpu_engine_module, inst, 0, mid_loop=mid_loop)
+    assert res.status == "optimal" and res.objective == em["objective"]
+    assert res.stats["pivots"] == em["pivots"] and res.stats["cycle_arcs"] == em["cycle_arcs"]
+    assert res.stats["cycle_scans"] == em["scans"]
+    assert np.array_equal(res.flow, em["flow"]) and np.array_equal(res.potential, em["potential"])
+    for key in ("order", "parent", "size", "depth", "psize"):
+        assert np.array_equal(tree[key], em[key]), key
+    check_optimality(inst, res.flow, res.potential)
+
+
 # ------------------------------------------------------------------ golden fixtures, through the reference-shaped API
 @pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
 @pytest.mark.parametrize("strategy", ["dantzig", "devex", "adaptive", "candidate_list"])
