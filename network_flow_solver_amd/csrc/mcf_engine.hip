@@ -277,12 +277,14 @@ constexpr int kMaxRcupdBlocks = 1024;
 // posbuf[cur^1], pi and the depths of T2; the update half writes rcache.  One launch boundary less per pivot.
 // `c` is the control block (kernel argument memory / LDS); the pass is spread over `stride` lanes of which this
 // one is `tid`, and over `ngroups` 16-lane groups of which this lane belongs to `group` (sub-lane `sub`).
-__device__ __forceinline__ void update_pass(const McfView& v, const McfCtx& c, int64_t tid, int64_t stride, int64_t group,
-                                            int64_t ngroups, int32_t sub) {
+__device__ __forceinline__ void apply_pass(const McfView& v, const McfCtx& c, int64_t tid, int64_t stride) {
     const int32_t lo = c.lo, hi = c.hi, plo = c.prev_lo, phi = c.prev_hi;
     for (int64_t j = lo + tid; j < hi; j += stride) mcf_apply_one(v, c, (int32_t)j);
     for (int64_t j = plo + tid; j < phi; j += stride)
         if (j < lo || j >= hi) mcf_apply_one(v, c, (int32_t)j);
+}
+
+__device__ __forceinline__ void rcupd_pass(const McfView& v, const McfCtx& c, int64_t group, int64_t ngroups, int32_t sub) {
     if (!v.rcache) return;
     const int32_t a0 = c.t2_old, S = c.t2_size;
     const int64_t sigma = c.sigma;
@@ -303,12 +305,18 @@ __device__ __forceinline__ void update_pass(const McfView& v, const McfCtx& c, i
     }
 }
 
-__global__ __launch_bounds__(kRcupdThreads) void k_update(McfView v) {
+// The two halves are independent, and each is a chain of dependent loads: different workgroups run them side
+// by side (the first `apply_blocks` the permutation, the others the reduced-cost patch) instead of one after the other.
+__global__ __launch_bounds__(kRcupdThreads) void k_update(McfView v, int apply_blocks) {
     const McfCtx c = *v.ctx;  // uniform: scalar loads
     if (!c.apply) return;
-    update_pass(v, c, (int64_t)blockIdx.x * kRcupdThreads + threadIdx.x, (int64_t)gridDim.x * kRcupdThreads,
-                (int64_t)blockIdx.x * (kRcupdThreads / 16) + (threadIdx.x >> 4), (int64_t)gridDim.x * (kRcupdThreads / 16),
-                threadIdx.x & 15);
+    const int b = blockIdx.x;
+    if (b < apply_blocks) {
+        apply_pass(v, c, (int64_t)b * kRcupdThreads + threadIdx.x, (int64_t)apply_blocks * kRcupdThreads);
+    } else {
+        const int64_t rb = b - apply_blocks, nrb = (int64_t)gridDim.x - apply_blocks;
+        rcupd_pass(v, c, rb * (kRcupdThreads / 16) + (threadIdx.x >> 4), nrb * (kRcupdThreads / 16), threadIdx.x & 15);
+    }
 }
 
 // ------------------------------------------------------------------ k_reduce (multi-GPU: local best -> 16 bytes)
@@ -529,7 +537,10 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
         MCF_PSTAMP(1);
         pivot_core(v, S, key, arc, rule, priced);
         __syncthreads();  // the finish pass's writes (records, sizes, segment table) before the apply pass reads them
-        if (S.ctx.apply) update_pass(v, S.ctx, threadIdx.x, kPivotThreads, threadIdx.x >> 4, kPivotThreads / 16, threadIdx.x & 15);
+        if (S.ctx.apply) {  // (splitting the lanes between the two halves was measured and lost at 4 096 nodes)
+            apply_pass(v, S.ctx, threadIdx.x, kPivotThreads);
+            rcupd_pass(v, S.ctx, threadIdx.x >> 4, kPivotThreads / 16, threadIdx.x & 15);
+        }
         __syncthreads();
         MCF_PSTAMP(10);
 #ifdef MCF_STAMPS
@@ -1008,8 +1019,7 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
 
 void launch_apply(mcf_handle* h, hipStream_t s) {
     if (h->rcached) {  // tree/potential update and reduced-cost update in one launch
-        const int grid = h->apply_blocks > h->rcupd_blocks ? h->apply_blocks : h->rcupd_blocks;
-        hipLaunchKernelGGL(k_update, dim3(grid), dim3(kRcupdThreads), 0, s, h->view);
+        hipLaunchKernelGGL(k_update, dim3(h->apply_blocks + h->rcupd_blocks), dim3(kRcupdThreads), 0, s, h->view, h->apply_blocks);
     } else {
         hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
     }
