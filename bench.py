@@ -77,13 +77,17 @@ def run_pivots(eng, count: int):
     return restarts
 
 
-def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pass: bool = True) -> dict:
+def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pass: bool = True, full_sweeps: int = 1) -> dict:
+    """full_sweeps=1: every Dantzig / candidate-list sweep prices every arc (BASELINE.json's "full-scan" configs and
+    the roofline measurement); 0: the engine's default, which from 4 M arcs on skips pricing workgroups whose arcs have
+    not changed since they last swept them (same entering arcs, fewer bytes)."""
     import torch
 
     from network_flow_solver_amd import engine
 
     inst = make_instance(workload)
-    eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, device=0)
+    eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, device=0,
+                           full_sweeps=full_sweeps)
     run_pivots(eng, warmup)
     s0 = eng.stats()
     torch.cuda.synchronize()
@@ -94,9 +98,13 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
     s1 = eng.stats()
     pivots = s1["pivots"] - s0["pivots"] if restarts == 0 else steps
     arcs = s1["arcs_priced"] - s0["arcs_priced"] if restarts == 0 else steps * inst.m
+    # arcs whose reduced cost was actually read: the grid sweeps count them per workgroup (kernel-per-phase path);
+    # the single-workgroup loops read every arc they cover
+    swept = s1["arcs_swept"] - s0["arcs_swept"] if (restarts == 0 and s1.get("pricing_mode") == 1 and rule != 1) else arcs
     out = {
         "workload": f"{inst.name}: {inst.n} nodes / {inst.m} arcs", "n": inst.n, "m": inst.m,
-        "pivots": int(pivots), "seconds": dt, "pivots_per_sec": pivots / dt, "arcs_priced_per_sec": arcs / dt,
+        "pivots": int(pivots), "seconds": dt, "pivots_per_sec": pivots / dt, "arcs_priced_per_sec": swept / dt,
+        "arcs_covered_per_sec": arcs / dt, "incremental_sweeps": bool(swept < 0.98 * arcs),
         "ms_per_step": 1e3 * dt / max(pivots, 1), "restarts": restarts,
     }
     # dominant-kernel timing: HIP events on the engine's stream around every kernel of the same
@@ -104,7 +112,7 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
     if profile_pass:
         eng.close()
         eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, device=0,
-                               profile=True)
+                               profile=True, full_sweeps=full_sweeps)
         run_pivots(eng, warmup)
         p0 = eng.stats()
         run_pivots(eng, steps)
@@ -205,6 +213,7 @@ def main():
         "config": {"workload": head["workload"],
                    "pricing": {0: "full-scan Dantzig", 1: "block-search Devex", 2: "candidate list"}[rule],
                    "step": "one pivot (price + ratio test + tree/potential update)", "parallelism": "1 GPU",
+                   "sweeps": "full (every arc priced every pivot)",
                    "restarts_in_timed_region": head["restarts"]},
         "roofline": head.get("roofline"), "kernel_ms": head.get("kernel_ms"),
         "reference_published": {"pivots_per_sec": 52, "instance": "netgen_8_08a (real file)", "hardware": "unstated CPU",
@@ -225,15 +234,23 @@ def main():
         except Exception as exc:  # measurement aid only
             line["hbm_point"]["measured_copy_GBps"] = None
             line["hbm_point"]["copy_error"] = str(exc)
+        # the engine's default at this size: incremental sweeps (same entering arcs; fewer arcs read per pivot)
+        inc = measure_single("netgen_1m_16m", 2000, 200, rule, profile_pass=False, full_sweeps=0)
+        line["hbm_point"]["incremental_sweeps"] = {
+            "pivots_per_sec": inc["pivots_per_sec"], "ms_per_step": inc["ms_per_step"], "steps": inc["pivots"],
+            "arcs_read_per_sec": inc["arcs_priced_per_sec"], "arcs_covered_per_sec": inc["arcs_covered_per_sec"],
+            "note": "a pricing workgroup whose arcs did not change since it last swept them keeps its candidate; the entering "
+                    "arc is still the arg-max over all arcs (pivot sequence identical, asserted by the GPU tests)"}
     if not args.no_hbm_point and workload == "netgen_8_08a":
         # the other single-GPU-runnable BASELINE.json configs, measured the same way (no profiled pass)
         pts = []
         for wl, r, label in (("gridgen_8_14a", 1, "configs[2]: gridgen_8_14a, block-search Devex"),
                              ("goto_8_16a", 0, "configs[3] shape on 1 GPU: goto_8_16a, full-scan Dantzig"),
                              ("netgen_1m_16m", 2, "configs[4] shape on 1 GPU, candidate-list rule (the reference's default family)")):
-            m_ = measure_single(wl, 2000, 200, r, profile_pass=False)
+            m_ = measure_single(wl, 2000, 200, r, profile_pass=False, full_sweeps=0)  # engine defaults
             pts.append({"config": label, "workload": m_["workload"], "pivots_per_sec": m_["pivots_per_sec"],
-                        "arcs_priced_per_sec": m_["arcs_priced_per_sec"], "ms_per_step": m_["ms_per_step"], "steps": m_["pivots"]})
+                        "arcs_priced_per_sec": m_["arcs_priced_per_sec"], "arcs_covered_per_sec": m_["arcs_covered_per_sec"],
+                        "ms_per_step": m_["ms_per_step"], "steps": m_["pivots"]})
         line["config_points"] = pts
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(workload)

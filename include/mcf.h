@@ -85,14 +85,15 @@ typedef struct mcf_options {
                                 trips, then finish by the position-space scan (1 = scan only) */
     int32_t mid_loop;        /* persistent single-workgroup pivot loop for mid-size instances (k_solve_mid):
                                 0 = auto (by size and rule), -1 = never, 1 = whenever the handle allows it */
-    int32_t reserved;
+    int32_t full_sweeps;     /* incremental Dantzig / candidate-list sweeps (a pricing workgroup whose arcs have not changed since
+                                it last swept them keeps its candidate): 0 = auto (from 4 M arcs), 1 = never, -1 = always */
 } mcf_options;
 
 typedef struct mcf_stats {
     int64_t pivots;           /* FlowResult.iterations (degenerate pivots included) */
     int64_t degenerate;       /* theta == 0 */
     int64_t bound_flips;      /* leaving arc == entering arc */
-    int64_t arcs_priced;      /* sum over pricing passes of arcs whose rc was evaluated */
+    int64_t arcs_priced;      /* sum over pricing passes of the arcs the pass covers */
     int64_t nodes_moved;      /* preorder positions rewritten by the apply pass */
     int64_t subtree_nodes;    /* sum of re-hung subtree sizes */
     int64_t cycle_arcs;       /* sum of cycle lengths */
@@ -114,6 +115,7 @@ typedef struct mcf_stats {
                                  3 = persistent single-workgroup loop over global memory (k_solve_mid) */
     int64_t cycle_scans;      /* pivots whose cycle was completed by the position-space scan */
     int64_t scan_rounds;      /* chunk iterations of those scans */
+    int64_t arcs_swept;       /* arcs whose reduced cost the grid sweeps actually read (<= arcs_priced with incremental pricing) */
 } mcf_stats;
 
 /* Called from mcf_solve every cb_interval pivots (simplex.py:1143-1154).

@@ -155,7 +155,7 @@ struct McfCtx {
     int64_t degenerate;        // pivots with theta == 0
     int64_t bound_flips;       // pivots whose leaving arc is the entering arc (tree unchanged)
     int64_t max_pivots;
-    int64_t arcs_priced;       // sum of arcs whose reduced cost was evaluated
+    int64_t arcs_priced;       // sum over pricing passes of the arcs the pass covers (clean blocks of an incremental sweep included)
     int64_t nodes_moved;       // sum of preorder positions rewritten (diagnostic)
     int64_t subtree_nodes;     // sum of |T2| (diagnostic)
     int64_t cycle_arcs;        // sum of cycle lengths (diagnostic)
@@ -237,6 +237,20 @@ struct McfView {
     // cycle can be found by a coalesced team-wide scan over preorder positions instead of a pointer
     // chase whose length is the tree depth (mcf_pivot_scan).
     int32_t* psz[2];        // [n_nodes] each
+    // ---- incremental pricing (nullptr = every sweep prices every block).  A pricing workgroup's best candidate
+    // only changes when an arc of its block changes reduced cost or state; the passes that change arcs raise the
+    // block's flag, and a full Dantzig sweep (also the candidate-list rule's) skips the blocks whose flag is down.
+    // (one pointer only: the view travels in scalar registers, and 136 more bytes of it cost every kernel ~1.3 us)
+    struct McfDirty* dirty;
+};
+
+#define MCF_MAX_PRICE_BLOCKS 2048
+struct McfDirty {
+    int32_t nlb;                      // pricing workgroups per bucket
+    int32_t lo[MCF_NUM_BUCKETS];      // first engine arc of this rank's share of bucket x (full-sweep slicing)
+    int32_t hi[MCF_NUM_BUCKETS];      // one past its last
+    int32_t pad[3];
+    int32_t flag[MCF_MAX_PRICE_BLOCKS];  // != 0: the workgroup has to sweep its block again
 };
 
 MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc) {
@@ -244,6 +258,26 @@ MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc
 }
 
 MCF_HD int64_t mcf_pack_arc(int32_t orig, int64_t engine_idx) { return ((int64_t)orig << 32) | engine_idx; }
+
+// The pricing workgroup that sweeps engine arc e (k_price_rc / k_price: workgroup lb * 8 + x takes the groups of
+// four arcs  g_lo(x) + lb * 256 + lane + j * nlb * 256  of bucket x), or -1 when e is another rank's arc.
+MCF_HD int32_t mcf_price_block_of(const McfView& v, const McfDirty* d, int64_t e) {
+    int32_t x = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 1; k < MCF_NUM_BUCKETS; ++k) x += e >= v.bucket_off[k] ? 1 : 0;
+    const int32_t plo = d->lo[x], phi = d->hi[x];
+    if (e < plo || e >= phi) return -1;
+    const int32_t q = (int32_t)(e >> 2) - (plo >> 2);
+    return ((q >> 8) % d->nlb) * MCF_NUM_BUCKETS + x;
+}
+MCF_HD void mcf_mark_dirty(const McfView& v, int64_t e) {
+    McfDirty* d = v.dirty;
+    if (!d || e >= v.m) return;
+    const int32_t b = mcf_price_block_of(v, d, e);
+    if (b >= 0) d->flag[b] = 1;
+}
 
 // The arcs one pricing pass of one rank looks at inside bucket x: the Devex block k of nb
 // (a Devex "block" is slice k of every bucket, so a block search spans all 8 XCDs), and of
@@ -769,7 +803,7 @@ MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane,
         if (lane == 0) v.arcw[e].flow += (int64_t)s * delta;
     }
     if (stage == 1) {
-        if (lane == 0) v.state[e] = (int8_t)(-s);
+        if (lane == 0) { v.state[e] = (int8_t)(-s); mcf_mark_dirty(v, e); }
         return;
     }
 
@@ -783,7 +817,8 @@ MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane,
     const int32_t S = c->t2_size, b = c->t2_new;
     if (lane == 0) {
         v.state[e] = 0;
-        if (c->pv_leave < v.m) v.state[c->pv_leave] = (int8_t)c->pv_leave_state;
+        mcf_mark_dirty(v, e);
+        if (c->pv_leave < v.m) { v.state[c->pv_leave] = (int8_t)c->pv_leave_state; mcf_mark_dirty(v, c->pv_leave); }
     }
     // subtree sizes outside T2: the old ancestors of q lose S, v_in and its ancestors gain S
     // (join and above keep their size)

@@ -45,14 +45,14 @@ def shard_slices(bucket_off, world: int, rank: int) -> list[tuple[int, int]]:
 class HipShardEngine:
     """Adapter: the HIP engine (C ABI) driven on torch's current stream."""
 
-    def __init__(self, inst, rule: int, rank: int, world: int, device: int, block_size: int = 0):
+    def __init__(self, inst, rule: int, rank: int, world: int, device: int, block_size: int = 0, full_sweeps: int = 0):
         import torch
 
         from . import engine
 
         self.torch = torch
         self.eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule,
-                                    block_size=block_size, device=device, shard=(rank, world))
+                                    block_size=block_size, device=device, shard=(rank, world), full_sweeps=full_sweeps)
         self.device = torch.device("cuda", device)
 
     def new_candidate_buffers(self, world: int):
@@ -179,7 +179,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
             inst = generators.goto_style(n1 * world, m1, seed=1, name=f"{wl}(synthetic,x{world})")
         else:
             inst = generators.netgen_style(n1 * world, m1 * world, seed=1, name=f"{wl}(synthetic,x{world})")
-        eng = HipShardEngine(inst, rule, rank, world, local_rank)
+        eng = HipShardEngine(inst, rule, rank, world, local_rank, full_sweeps=1)  # value counts every arc of every sweep: so price them all
         force = os.environ.get("MCF_BENCH_FORCE_DIST") == "1"  # 1-GPU rehearsal: still issue the collective
         loop = PivotLoop(eng, dist, world, batch=32, always_gather=force,
                          use_graph=os.environ.get("MCF_DIST_GRAPH", "1") == "1")  # MCF_DIST_GRAPH=0: eager loop

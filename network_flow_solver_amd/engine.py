@@ -51,7 +51,7 @@ class McfOptions(ctypes.Structure):
         ("batch_pivots", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("profile", ctypes.c_int32),
         ("block_size", ctypes.c_int64), ("shard_rank", ctypes.c_int64), ("shard_count", ctypes.c_int64),
         ("price_blocks", ctypes.c_int32), ("no_fused", ctypes.c_int32), ("no_rcache", ctypes.c_int32),
-        ("cycle_scan", ctypes.c_int32), ("mid_loop", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("cycle_scan", ctypes.c_int32), ("mid_loop", ctypes.c_int32), ("full_sweeps", ctypes.c_int32),
     ]
 
 
@@ -64,7 +64,7 @@ class McfStats(ctypes.Structure):
         ("pivot_ms", ctypes.c_double), ("apply_ms", ctypes.c_double), ("price_launches", ctypes.c_int64),
         ("pivot_launches", ctypes.c_int64), ("apply_launches", ctypes.c_int64), ("price_bytes", ctypes.c_int64),
         ("artificial_flow", ctypes.c_int64), ("pricing_mode", ctypes.c_int64),
-        ("cycle_scans", ctypes.c_int64), ("scan_rounds", ctypes.c_int64),
+        ("cycle_scans", ctypes.c_int64), ("scan_rounds", ctypes.c_int64), ("arcs_swept", ctypes.c_int64),
     ]
 
     def as_dict(self) -> dict:
@@ -148,7 +148,7 @@ class McfEngine:
     def __init__(self, n: int, tail, head, cost, cap, supply, rule: int = RULE_DANTZIG, block_size: int = 0,
                  batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
                  shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
-                 resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0):
+                 resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0, full_sweeps: int = 0):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -179,6 +179,7 @@ class McfEngine:
         opt.no_rcache = 0 if resident_rc else 1
         opt.cycle_scan = int(cycle_scan)
         opt.mid_loop = int(mid_loop)
+        opt.full_sweeps = int(full_sweeps)   # 0 auto, 1 never incremental, -1 always incremental
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule

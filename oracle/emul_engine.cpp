@@ -69,6 +69,7 @@ void bind(Emul& e) {
     v.rcache = nullptr;  // the emulation always prices by gathering potentials: an independent
     v.adj_off = nullptr; // check of the engine's resident reduced costs
     v.adj = nullptr;
+    v.dirty = nullptr;  // the emulation always sweeps everything: an independent check of the incremental sweeps
     v.posbuf[0] = im.pos.data();
     v.posbuf[1] = e.pos1.data();
     im.psize.resize((size_t)im.n_nodes + 4, 0);  // the scan reads whole groups of four positions

@@ -79,7 +79,8 @@ def test_resident_reduced_costs_stay_exact(gpu_engine_module, rule, mid_loop):
     stage of the solve; and the pivot sequence equals the gather-priced one."""
     _, inst = load_synthetic()[7]                                  # 1 024 nodes / 8 192 arcs: past the LDS path
     e = gpu_engine_module
-    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, mid_loop=mid_loop) as eng:
+    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, mid_loop=mid_loop,
+                     full_sweeps=-1) as eng:                       # incremental sweeps across budgets / resumes as well
         for budget in (0, 1, 5, 40, 300, 10 ** 9):
             if budget:
                 eng.solve(max_pivots=budget)
@@ -165,6 +166,25 @@ def test_persistent_loop_equals_kernel_per_phase_path(gpu_engine_module, name, r
     for key in ("order", "parent", "size", "pos", "depth", "psize"):
         assert np.array_equal(ta[key], tb[key]), key
     check_optimality(inst, a.flow, a.potential)
+
+
+@pytest.mark.parametrize("rule", [0, 2], ids=["dantzig", "candidate_list"])
+@pytest.mark.parametrize("name", ["netgen_8_12a", "gridgen_8_14a"])
+def test_incremental_sweeps_select_the_same_arcs(gpu_engine_module, name, rule):
+    """A pricing workgroup whose arcs have not changed since it last swept them keeps its candidate (the resident
+    reduced costs make "changed" exact: the arcs k_update patches + the entering / leaving arc).  The entering arc
+    is still the arg-max over ALL arcs: same pivot sequence as with full sweeps, a fraction of the arcs read."""
+    inst = generators.named_instance(name)
+    full, tf = _solve(gpu_engine_module, inst, rule, full_sweeps=1, mid_loop=-1)
+    inc, ti = _solve(gpu_engine_module, inst, rule, full_sweeps=-1, mid_loop=-1)
+    assert full.status == inc.status == "optimal" and full.objective == inc.objective
+    assert full.stats["pivots"] == inc.stats["pivots"] and full.stats["arcs_priced"] == inc.stats["arcs_priced"]
+    assert np.array_equal(full.flow, inc.flow) and np.array_equal(full.potential, inc.potential)
+    assert np.array_equal(tf["order"], ti["order"]) and np.array_equal(tf["parent"], ti["parent"])
+    assert full.stats["arcs_swept"] >= full.stats["arcs_priced"] * 0.95       # (block slices overlap by < one group of 4)
+    assert inc.stats["arcs_swept"] <= full.stats["arcs_swept"]
+    if rule == 0 and name == "gridgen_8_14a":                     # 64 pricing workgroups, small re-hung subtrees
+        assert inc.stats["arcs_swept"] < 0.7 * full.stats["arcs_swept"]
 
 
 def _chain_instance(n, skip=7):
