@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1; shift
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o run -- python3 $R/scripts/prof_solve.py "$@" > $out/stdout.log 2> $out/stderr.log
+MCF_USE_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o run -- python3 $R/scripts/prof_solve.py "$@" > $out/stdout.log 2> $out/stderr.log
 rc=$?
 tail -1 $out/stdout.log
 f=$(find $out -name '*kernel_stats.csv' | head -1)

@@ -1,6 +1,6 @@
 """One (partial) solve of a named instance, for rocprofv3 --kernel-trace --stats.
 usage: prof_solve.py INSTANCE [RULE] [MAX_PIVOTS] [CYCLE_SCAN]"""
-import json, sys, time
+import json, os, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
@@ -12,7 +12,7 @@ cap = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000_000
 cs = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 inst = generators.named_instance(name)
 with engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, cycle_scan=cs,
-                      use_graph=False) as eng:  # rocprofv3 crashes inside hipGraphLaunch on this image: eager launches
+                      use_graph=os.environ.get("MCF_USE_GRAPH", "1") != "0") as eng:  # (rocprofv3 needs MCF_USE_GRAPH=0: it faults inside hipGraphLaunch on this image)
     t0 = time.perf_counter()
     eng.solve(max_pivots=cap)
     dt = time.perf_counter() - t0
