@@ -191,6 +191,7 @@ struct McfCtx {
     int32_t pv_first, pv_second;  // end points of the entering arc in push order
     int64_t pv_rc;             // its exact reduced cost
     int64_t pv_cap;            // its capacity
+    int64_t pv_flow;           // its flow before the pivot
     int64_t pv_delta;
     // ---- cycle search: round trips the pointer-chasing climb may take before the position-space scan
     // takes over (only when the view carries psz[]); diagnostics
@@ -287,6 +288,7 @@ MCF_HD void mcf_mark_dirty(const McfView& v, int64_t e) {
 MCF_HD void mcf_bucket_slice(const int64_t* bucket_off, int x, int64_t r, int64_t G, int64_t k, int64_t nb,
                              int64_t* lo, int64_t* hi) {
     const int64_t s = bucket_off[x], len = bucket_off[x + 1] - s;
+    if (G == 1 && nb == 1) { *lo = s; *hi = s + len; return; }  // the whole bucket: no (emulated 64-bit) divisions
     const int64_t a = s + len * k / nb, b = s + len * (k + 1) / nb;
     const int64_t len2 = b - a;
     *lo = a + len2 * r / G;
@@ -418,7 +420,9 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
     const int64_t rc = v.rcache ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
 
     c->pv_e = e; c->pv_s = s; c->pv_first = first; c->pv_second = second; c->pv_rc = rc;
-    c->pv_cap = v.arcw[e].cap;
+    const McfArcW ae = v.arcw[e];  // one 16-byte load: capacity for the ratio test, flow for the store-only update
+    c->pv_cap = ae.cap;
+    c->pv_flow = ae.flow;
     return true;
 }
 
@@ -800,7 +804,7 @@ MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane,
             if (pp.flow1) v.arcw[p >> 1].flow = (side1 ? pp.flow1[i] : pp.flow2[i - n1]) + dlt;  // read by the hit pass already
             else v.arcw[p >> 1].flow += dlt;
         }
-        if (lane == 0) v.arcw[e].flow += (int64_t)s * delta;
+        if (lane == 0) v.arcw[e].flow = c->pv_flow + (int64_t)s * delta;  // (read in mcf_pivot_begin: no load here)
     }
     if (stage == 1) {
         if (lane == 0) { v.state[e] = (int8_t)(-s); mcf_mark_dirty(v, e); }

@@ -200,8 +200,44 @@ template <int RULE, bool FILTER, bool INC>
 __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t shard, int64_t shards, int use_block,
                                                              int64_t f_lo, int64_t f_hi, McfCand* __restrict__ cand,
                                                              int64_t* __restrict__ swept) {
-    int64_t key = 0, arc = -1;
+    // On small and mid-size instances this kernel is a latency chain (control block -> arc data -> ids -> arg-max),
+    // so: (1) the first batch of arc data is requested BEFORE the control block is looked at (full sweeps: the
+    // slice does not depend on it); (2) the caller's arc id, needed only to break ties and to name the winner, is
+    // looked up once per lane at the end instead of once per improvement.
     const McfCtx* c = v.ctx;
+    const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
+    const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+    using rc2_t = long2;                                  // two int64 reduced costs per 16-byte load
+    const rc2_t* __restrict__ rc2 = reinterpret_cast<const rc2_t*>(v.rcache);
+    const int32_t* __restrict__ state4 = reinterpret_cast<const int32_t*>(v.state);
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(v.weight);
+    const int32_t* __restrict__ orig = v.orig;
+    const int64_t stride = nlb * kPriceThreads;
+    constexpr int U = 4;
+    int32_t st[U];
+    rc2_t ra[U], rb[U];
+    float4 w[U];
+    int64_t lo = 0, hi = 0, g_lo = 0, g_hi = 0;
+    auto load_batch = [&](int64_t g0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t g = g0 + u * stride;
+            const bool in = g < g_hi;
+            const int64_t gs = in ? g : g_lo;  // clamp: keep the loads unconditional and in range
+            st[u] = in ? state4[gs] : 0;
+            ra[u] = rc2[2 * gs];
+            rb[u] = rc2[2 * gs + 1];
+            if (RULE == MCF_RULE_DEVEX_BLOCK) w[u] = w4[gs];
+        }
+    };
+    const bool early = use_block != 1;  // full sweep: the slice is known without the control block
+    int64_t g0 = 0;
+    if (early) {
+        mcf_bucket_slice(v.bucket_off, x, shard, shards, 0, 1, &lo, &hi);
+        g_lo = lo >> 2; g_hi = (hi + 3) >> 2;  // groups of 4 arcs
+        g0 = g_lo + lb * kPriceThreads + threadIdx.x;
+        if (g0 < g_hi) load_batch(g0);
+    }
     // candidate-list rule: while minor iterations are pending the list of the last sweep must
     // survive, so the whole launch is a no-op (use_block == 2 marks that rule)
     if (use_block == 2 && (c->minor_left > 0 || c->status != MCF_RUNNING)) return;  // (also: a finished batch's
@@ -209,13 +245,15 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
     // incremental full sweep: no arc of this block changed since the block was last swept -> cand[blockIdx.x] still
     // holds.  (A finished batch's trailing launches must leave the candidates alone too: a resumed solve relies on them.)
     if (INC && v.dirty && use_block != 1 && (c->status != MCF_RUNNING || !v.dirty->flag[blockIdx.x])) return;
+    int64_t key = 0, arc = -1;
+    int64_t best_i = -1;  // engine index of this lane's best arc (its caller's id is looked up at the end)
     if (c->status == MCF_RUNNING) {
-        const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
-        const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
-        int64_t lo, hi;
-        mcf_bucket_slice(v.bucket_off, x, shard, shards, use_block == 1 ? c->block_index : 0,
-                         use_block == 1 ? c->num_blocks : 1, &lo, &hi);
-        const int64_t g_lo = lo >> 2, g_hi = (hi + 3) >> 2;  // groups of 4 arcs
+        if (!early) {
+            mcf_bucket_slice(v.bucket_off, x, shard, shards, c->block_index, c->num_blocks, &lo, &hi);
+            g_lo = lo >> 2; g_hi = (hi + 3) >> 2;
+            g0 = g_lo + lb * kPriceThreads + threadIdx.x;
+            if (g0 < g_hi) load_batch(g0);
+        }
         if (INC && swept && threadIdx.x == 0) {
             // accounting off the critical path: 32-bit arithmetic, and a no-return atomic on the workgroup's private slot
             // (nothing waits for it; one shared word would serialise 2 048 atomics, ~10 us per sweep).
@@ -225,27 +263,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
             const uint32_t mine = full * 256u + (rem > off ? (rem - off < 256u ? rem - off : 256u) : 0u);
             atomicAdd(reinterpret_cast<unsigned long long*>(swept) + blockIdx.x, (unsigned long long)mine * 4ull);
         }
-        using rc2_t = long2;                                  // two int64 reduced costs per 16-byte load
-        const rc2_t* __restrict__ rc2 = reinterpret_cast<const rc2_t*>(v.rcache);
-        const int32_t* __restrict__ state4 = reinterpret_cast<const int32_t*>(v.state);
-        const float4* __restrict__ w4 = reinterpret_cast<const float4*>(v.weight);
-        const int32_t* __restrict__ orig = v.orig;
-        const int64_t stride = nlb * kPriceThreads;
-        constexpr int U = 4;
-        for (int64_t g0 = g_lo + lb * kPriceThreads + threadIdx.x; g0 < g_hi; g0 += stride * U) {
-            int32_t st[U];
-            rc2_t ra[U], rb[U];
-            float4 w[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t g = g0 + u * stride;
-                const bool in = g < g_hi;
-                const int64_t gs = in ? g : g_lo;
-                st[u] = in ? state4[gs] : 0;
-                ra[u] = rc2[2 * gs];
-                rb[u] = rc2[2 * gs + 1];
-                if (RULE == MCF_RULE_DEVEX_BLOCK) w[u] = w4[gs];
-            }
+        while (g0 < g_hi) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t rcs[4] = {ra[u].x, ra[u].y, rb[u].x, rb[u].y};
@@ -263,14 +281,19 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
                         const double merit = ((double)viol * (double)viol) / (double)ws[k];
                         kk = __double_as_longlong(merit);
                     }
-                    if (kk < key) continue;              // cannot win: skip the id lookup
-                    const int32_t o = orig[i];
-                    if (FILTER && (o < f_lo || o >= f_hi)) continue;
-                    const int64_t id = mcf_pack_arc(o, i);
-                    if (mcf_cand_better(kk, id, key, arc)) { key = kk; arc = id; }
+                    if (kk < key) continue;
+                    if (FILTER) {  // parity hook: the caller's index range decides eligibility
+                        const int32_t o = orig[i];
+                        if (o < f_lo || o >= f_hi) continue;
+                    }
+                    if (kk > key) { key = kk; best_i = i; }
+                    else if (best_i < 0 || orig[i] < orig[best_i]) best_i = i;  // tie on the key (rare): lowest caller's index
                 }
             }
+            g0 += stride * U;
+            if (g0 < g_hi) load_batch(g0);
         }
+        if (best_i >= 0) arc = mcf_pack_arc(orig[best_i], best_i);
     }
     block_argmax<kPriceThreads>(key, arc);
     if (threadIdx.x == 0) {
