@@ -565,20 +565,48 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
             const int64_t lo = s_lo[row + x], hi = s_hi[row + x];
             const int64_t* __restrict__ rcache = v.rcache;
             const int8_t* __restrict__ state = v.state;
-            for (int64_t i = lo + l; i < hi; i += kPer) {
-                const int32_t st = state[i];
-                if (!st) continue;
-                const int64_t viol = -(int64_t)st * rcache[i];
-                if (viol <= 0) continue;
-                int64_t kk = viol;
-                if (rule == MCF_RULE_DEVEX_BLOCK) {
-                    const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
-                    kk = __double_as_longlong(merit);
+            int64_t best_i = -1;  // the caller's id is looked up once at the end (and on ties)
+            constexpr int UM = 4;  // arcs in flight per lane: all loads first (unconditional, clamped), then the arithmetic
+            if (hi - lo <= kPer) {  // at most one arc per lane (small Devex blocks): nothing to overlap
+                const int64_t i = lo + l;
+                if (i < hi && state[i]) {
+                    const int64_t viol = -(int64_t)state[i] * rcache[i];
+                    if (viol > 0) {
+                        key = viol;
+                        if (rule == MCF_RULE_DEVEX_BLOCK) key = __double_as_longlong(((double)viol * (double)viol) / (double)v.weight[i]);
+                        best_i = i;
+                    }
                 }
-                if (kk < key) continue;
-                const int64_t id = mcf_pack_arc(v.orig[i], i);
-                if (mcf_cand_better(kk, id, key, arc)) { key = kk; arc = id; }
+            } else
+            for (int64_t i0 = lo + l; i0 < hi; i0 += (int64_t)kPer * UM) {
+                int32_t sts[UM];
+                int64_t rcs[UM];
+                float wts[UM];
+#pragma unroll
+                for (int u = 0; u < UM; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kPer;
+                    const int64_t ic = i < hi ? i : lo;
+                    sts[u] = i < hi ? (int32_t)state[ic] : 0;
+                    rcs[u] = rcache[ic];
+                    wts[u] = rule == MCF_RULE_DEVEX_BLOCK ? v.weight[ic] : 1.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < UM; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kPer;
+                    if (!sts[u]) continue;
+                    const int64_t viol = -(int64_t)sts[u] * rcs[u];
+                    if (viol <= 0) continue;
+                    int64_t kk = viol;
+                    if (rule == MCF_RULE_DEVEX_BLOCK) {
+                        const double merit = ((double)viol * (double)viol) / (double)wts[u];
+                        kk = __double_as_longlong(merit);
+                    }
+                    if (kk < key) continue;
+                    if (kk > key) { key = kk; best_i = i; }
+                    else if (best_i < 0 || v.orig[i] < v.orig[best_i]) best_i = i;
+                }
             }
+            if (best_i >= 0) arc = mcf_pack_arc(v.orig[best_i], best_i);
             if (threadIdx.x == 0)
                 for (int x2 = 0; x2 < MCF_NUM_BUCKETS; ++x2) priced += s_hi[row + x2] - s_lo[row + x2];
             block_argmax<kPivotThreads>(key, arc);
