@@ -156,3 +156,19 @@ def test_warm_start_without_bound_information_still_reaches_the_optimum():
         r = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, warm_in_tree=it)
         assert r["status"] == "optimal" and r["objective"] == cold["objective"]
         check_optimality(inst, r["flow"], r["potential"])
+
+
+def test_cycle_scan_above_65535_nodes():
+    """Scan vs climb, pivot for pivot, on 70 000 nodes (several scan rounds per pivot on the device; a halfword
+    variant of the position-space sizes was measured and dropped -- this size is where it would saturate)."""
+    from network_flow_solver_amd import generators
+    inst = generators.netgen_style(70000, 280000, seed=3)
+    kw = dict(rule=0, trace=4000, max_pivots=1500)
+    a = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, climb_budget=-1, **kw)
+    b = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, climb_budget=0, **kw)
+    assert a["pivots"] == b["pivots"] == 1500 and b["scans"] > 0
+    assert np.array_equal(a["trace"], b["trace"]) and np.array_equal(a["flow"], b["flow"])
+    for key in ("parent", "size", "pos", "order", "depth", "psize"):
+        assert np.array_equal(a[key], b[key]), key
+    assert b["psize"][0] == inst.n + 1 > 65535
+    check_tree_invariants(inst.n, b["parent"], b["size"], b["pos"], b["order"], b["depth"], b["psize"])

@@ -187,6 +187,26 @@ def test_incremental_sweeps_select_the_same_arcs(gpu_engine_module, name, rule):
         assert inc.stats["arcs_swept"] < 0.7 * full.stats["arcs_swept"]
 
 
+def test_cycle_scan_above_65535_nodes(gpu_engine_module):
+    """70 000 nodes (several scan rounds per pivot): scan vs climb after 6 000 pivots, and both against the CPU
+    emulation."""
+    inst = generators.netgen_style(70000, 280000, seed=3)
+    e = gpu_engine_module
+    out = {}
+    for cs in (-1, 0):
+        with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0, cycle_scan=cs) as eng:
+            eng.solve(max_pivots=6000)
+            out[cs] = (eng.result(), eng.tree())
+    (a, ta), (b, tb) = out[-1], out[0]
+    em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0, max_pivots=6000, climb_budget=0)
+    assert a.stats["pivots"] == b.stats["pivots"] == em["pivots"] == 6000 and b.stats["cycle_scans"] > 0
+    assert np.array_equal(a.flow, b.flow) and np.array_equal(b.flow, em["flow"]) and np.array_equal(b.potential, em["potential"])
+    for key in ("order", "parent", "size", "depth"):
+        assert np.array_equal(ta[key], tb[key]) and np.array_equal(tb[key], em[key]), key
+    assert np.array_equal(tb["psize"], em["psize"]) and tb["psize"][0] == inst.n + 1
+    check_tree_invariants(inst.n, tb["parent"], tb["size"], tb["pos"], tb["order"], tb["depth"], tb["psize"])
+
+
 def _chain_instance(n, skip=7):
     """A path 0 -> 1 -> ... -> n-1 with capacity 10, shortcut arcs every `skip` nodes and one expensive direct
     arc; 15 units from 0 to n-1.  The optimal tree is essentially the path: cycles thousands of arcs long (the
