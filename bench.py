@@ -138,9 +138,12 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         except Exception:
             pass
         out["roofline"] = {
-            "kernel": kname, "bound": "hbm",
+            "kernel": kname, "bound": "hbm", "workload": out["workload"],
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": int(bytes_per_launch),
+            # the same launch time against the bytes the PMC counters saw (None when no PMC pass covers this workload)
+            "traffic_GBps": (traffic / (sweep_ms * 1e-3) / 1e9) if traffic else None,
+            "traffic_frac_of_peak": (traffic / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
             "ms_per_launch": sweep_ms, "ms_per_launch_in_pivot_loop": price_ms,
             "note": "achieved = SURVEY section 8d algorithmic bytes (13 B/arc + 8 B/node) / launch time; the resident-rc "
                     "sweep really moves 9 B/arc, so achieved can exceed the physical peak" if mode == 1 else
