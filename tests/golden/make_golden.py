@@ -362,5 +362,24 @@ def main():
     print("done")
 
 
+def extra():
+    """Append the larger instances (minutes of reference time each) to the existing synthetic.json without
+    regenerating the rest:  python3 tests/golden/make_golden.py --extra"""
+    syn = json.loads((HERE / "synthetic.json").read_text())
+    have = {e["name"] for e in syn}
+    todo = [
+        generators.gridgen_style(32, 32, seed=1, name="gridgen_8_10a(synthetic)"),
+        generators.goto_style(32, 32, seed=1, name="goto_8_10a(synthetic)"),
+        generators.netgen_style(2048, 16384, seed=1, name="netgen_8_11a(synthetic)"),
+        generators.named_instance("netgen_8_12a"),
+    ]
+    for inst in todo:
+        if inst.name in have:
+            continue
+        syn.append(synthetic_entry(inst, strategies=("devex",)))
+        (HERE / "synthetic.json").write_text(json.dumps(syn, indent=1))
+    print("done")
+
+
 if __name__ == "__main__":
-    main()
+    extra() if "--extra" in sys.argv else main()
