@@ -1,20 +1,25 @@
 // mcf_engine.hip -- MI355X (gfx950) network-simplex pivot engine: HIP kernels + C ABI.
 //
-// One pivot = three kernels on one stream (no host round trip in between):
+// One pivot, by instance size (mcf_create picks; all paths share mcf_core.h and give the same pivot sequence):
 //
-//   k_price   grid-wide reduced-cost sweep over the arc SoA: coalesced 16-byte loads of
-//             tail/head/cost (+4 state bytes), gathers of pi[tail], pi[head], per-lane
-//             best, wavefront xor-shuffle arg-max, one candidate per workgroup.
-//             HBM-bound: 13 B/arc (+4 B/arc Devex weight) + 8 B per distinct node.
-//             Replaces simplex.py:498-617 and simplex_pricing.py:97-137, 310-357.
-//   k_pivot   one workgroup: final arg-max over the workgroup candidates (or the candidates
-//             all-gathered from the other ranks), then ONE lane runs mcf_pivot_walk (join +
-//             ratio test: O(cycle) dependent loads) and ALL lanes mcf_pivot_finish (flow update,
-//             stem re-parenting, segment table: one path element per lane).
-//             Replaces basis.py:178-241 and simplex.py:1198-1425.
-//   k_apply   grid-wide block permutation of the preorder array for the re-hung subtree +
-//             its potential shift (pi += sigma) + pos rewrite.  Replaces the per-pivot
-//             BFS rebuild (basis.py:82-122) and _update_tree_sets (simplex.py:1103-1107).
+//   k_solve_small   whole instance in LDS: one persistent workgroup prices, pivots (two lanes climb the cycle in
+//                   lock step) and updates until the solve ends.
+//   k_solve_mid     <= 8 192 nodes: one persistent workgroup over global (L2-resident) state -- prices a Devex
+//                   block / re-prices the candidate list / sweeps a small arc list, pivots, permutes, patches.
+//   otherwise three kernels per pivot on one stream, 64 pivots per captured hipGraph:
+//     k_price_rc    grid-wide stream over RESIDENT reduced costs (8 B rc + 1 B state per arc, +4 B Devex weight):
+//                   per-lane best, DPP wave max, one candidate per workgroup.  HBM-bound at scale.  Incremental
+//                   from 4 M arcs: workgroups whose arcs did not change keep their candidate.
+//                   (k_price: the same sweep by gathering pi[tail], pi[head]; mode 0 / parity hook.)
+//                   Replaces simplex.py:498-617 and simplex_pricing.py:97-137, 310-357, 375-542.
+//     k_pivot       one workgroup of 1024: final arg-max over the workgroup candidates (or the candidates
+//                   all-gathered from the other ranks), cycle by a workgroup-wide scan over preorder positions
+//                   (mcf_pivot_scan; climb above 2^20 nodes), ratio test, then mcf_pivot_finish on all lanes (flow
+//                   update, stem re-parenting, segment table).  Replaces basis.py:178-241, simplex.py:1198-1425.
+//     k_update      grid-wide block permutation of the preorder array + potential shift (pi += sigma) + position /
+//                   size rewrite, and -- in other workgroups of the same launch -- the patch of the resident
+//                   reduced costs of the arcs incident to the re-hung subtree.  Replaces the per-pivot BFS
+//                   rebuild (basis.py:82-122) and _update_tree_sets (simplex.py:1103-1107).
 //
 // The host enqueues `batch_pivots` pivots (optionally as one captured hipGraph), then
 // reads the small control block back once.  Kernels of a finished solve early-exit.
