@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shar
 template <int RULE, bool FILTER, bool INC>
 __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t shard, int64_t shards, int use_block,
                                                              int64_t f_lo, int64_t f_hi, McfCand* __restrict__ cand,
-                                                             int64_t* __restrict__ swept) {
+                                                             int64_t* __restrict__ swept, const int32_t* __restrict__ blk_tab) {
     // On small and mid-size instances this kernel is a latency chain (control block -> arc data -> ids -> arg-max),
     // so: (1) the first batch of arc data is requested BEFORE the control block is looked at (full sweeps: the
     // slice does not depend on it); (2) the caller's arc id, needed only to break ties and to name the winner, is
@@ -254,7 +254,10 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
     int64_t best_i = -1;  // engine index of this lane's best arc (its caller's id is looked up at the end)
     if (c->status == MCF_RUNNING) {
         if (!early) {
-            mcf_bucket_slice(v.bucket_off, x, shard, shards, c->block_index, c->num_blocks, &lo, &hi);
+            // Devex block search: this rank's share of block k of bucket x -- tabulated by the host (four emulated
+            // 64-bit divisions otherwise, ~0.8 us on this kernel's critical path)
+            if (blk_tab) { const int64_t k = c->block_index; lo = blk_tab[(k * MCF_NUM_BUCKETS + x) * 2]; hi = blk_tab[(k * MCF_NUM_BUCKETS + x) * 2 + 1]; }
+            else mcf_bucket_slice(v.bucket_off, x, shard, shards, c->block_index, c->num_blocks, &lo, &hi);
             g_lo = lo >> 2; g_hi = (hi + 3) >> 2;
             g0 = g_lo + lb * kPriceThreads + threadIdx.x;
             if (g0 < g_hi) load_batch(g0);
@@ -455,7 +458,7 @@ __device__ __forceinline__ int64_t devex_block_arcs(const McfView& v, const McfC
 
 template <bool MARK>  // MARK: the handle prices incrementally, the entering / leaving arc's blocks are flagged
 __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCand* __restrict__ cand, int ncand,
-                                                          int32_t rule, int have_sweep) {
+                                                          int32_t rule, int have_sweep, const int64_t* __restrict__ blk_total) {
     __shared__ PivotShared S;
 #ifdef MCF_STAMPS
     if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = __builtin_amdgcn_s_memtime(); }
@@ -478,6 +481,11 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     // candidate-list rule, minor iteration: no sweep ran; the listed arcs are re-priced here
     // against the current state (resident reduced cost or potentials)
     const bool minor = rule == MCF_RULE_CANDIDATE_LIST && S.ctx.minor_left > 0;
+    // accounting: arcs this pass covers over ALL shards.  Devex: the block's size comes from a host-made table (its
+    // load is in flight during the arg-max; computing it costs 32 emulated 64-bit divisions, ~3 us of lane 0's time)
+    int64_t priced = minor ? ncand : v.m;
+    if (threadIdx.x == 0 && rule == MCF_RULE_DEVEX_BLOCK && S.ctx.num_blocks > 1)
+        priced = blk_total ? blk_total[S.ctx.block_index] : devex_block_arcs(v, S.ctx);
     for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
         const McfCand cd = i == (int)threadIdx.x ? first : cand[i];
         const int64_t kk = minor ? mcf_minor_key(v, cd.arc) : cd.key;
@@ -489,8 +497,6 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
         block_argmax<kPivotThreads>(key, arc);
     }
     MCF_PSTAMP(1);
-    int64_t priced = minor ? ncand : v.m;  // full sweep: every arc (no 64-bit divisions on the hot path)
-    if (threadIdx.x == 0 && rule == MCF_RULE_DEVEX_BLOCK && S.ctx.num_blocks > 1) priced = devex_block_arcs(v, S.ctx);
     pivot_core(v, S, key, arc, rule, priced);
     // publish the control block for the apply / pricing launches that follow (finish only reads it)
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&S.ctx)[threadIdx.x];
@@ -978,6 +984,8 @@ struct mcf_handle {
     int32_t *d_pos0 = nullptr, *d_pos1 = nullptr, *d_psz0 = nullptr, *d_psz1 = nullptr;
     McfDirty* d_dirty = nullptr;
     int64_t* d_swept = nullptr;  // arcs swept per pricing workgroup (summed by mcf_get_result)
+    int32_t* d_blk_tab = nullptr;  // Devex: (lo, hi) of this rank's share of block k of bucket x, [num_blocks][8][2]
+    int64_t* d_blk_total = nullptr;  // Devex: arcs of block k over all shards (accounting)
     bool rcached = false;     // large instance: resident reduced costs + k_rcupd
     int rcupd_blocks = 1;
     McfSeg* d_seg = nullptr;
@@ -1066,6 +1074,27 @@ int upload_image(mcf_handle* h) {
     c.minor_cap = mcf_minor_cap(h->price_blocks);
     c.climb_budget = h->climb_budget;
     *h->h_ctx = c;
+    if (h->opt.rule == MCF_RULE_DEVEX_BLOCK && c.num_blocks <= 4096 && !h->d_blk_tab) {  // block bounds, once
+        std::vector<int32_t> tab((size_t)c.num_blocks * MCF_NUM_BUCKETS * 2);
+        for (int64_t k = 0; k < c.num_blocks; ++k)
+            for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+                int64_t lo, hi;
+                mcf_bucket_slice(im.bucket_off, x, h->shard, h->shards, k, c.num_blocks, &lo, &hi);
+                tab[(k * MCF_NUM_BUCKETS + x) * 2] = (int32_t)lo;
+                tab[(k * MCF_NUM_BUCKETS + x) * 2 + 1] = (int32_t)hi;
+            }
+        if (dalloc(&h->d_blk_tab, tab.size()) != hipSuccess) { h->err = "hipMalloc block table"; return MCF_E_ALLOC; }
+        HIP_TRY(h, hipMemcpy(h->d_blk_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        std::vector<int64_t> total(c.num_blocks, 0);
+        for (int64_t k = 0; k < c.num_blocks; ++k)
+            for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+                int64_t lo, hi;
+                mcf_bucket_slice(im.bucket_off, x, 0, 1, k, c.num_blocks, &lo, &hi);
+                total[k] += hi - lo;
+            }
+        if (dalloc(&h->d_blk_total, total.size()) != hipSuccess) { h->err = "hipMalloc block table"; return MCF_E_ALLOC; }
+        HIP_TRY(h, hipMemcpy(h->d_blk_total, total.data(), total.size() * 8, hipMemcpyHostToDevice));
+    }
     HIP_TRY(h, hipMemcpyAsync(h->d_ctx, h->h_ctx, sizeof(McfCtx), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     // per-pass accounting: a Devex pass prices one block of the shard, Dantzig the whole shard
@@ -1093,10 +1122,10 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
     if (rule == MCF_RULE_CANDIDATE_LIST && use_block) use_block = 2;
     if (h->rcached) {
         if (rule == MCF_RULE_DEVEX_BLOCK)
-            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept);
+            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, use_block == 1 ? h->d_blk_tab : nullptr);
         else
-            if (v.dirty) hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, true>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept);
-            else hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept);
+            if (v.dirty) hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, true>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)nullptr);
+            else hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)nullptr);
     } else {
         if (rule == MCF_RULE_DEVEX_BLOCK)
             hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out);
@@ -1106,8 +1135,8 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
 }
 
 void launch_k_pivot(mcf_handle* h, hipStream_t s, const McfCand* cand, int ncand, int32_t rule, int have_sweep) {
-    if (h->view.dirty) hipLaunchKernelGGL(k_pivot<true>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep);
-    else hipLaunchKernelGGL(k_pivot<false>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep);
+    if (h->view.dirty) hipLaunchKernelGGL(k_pivot<true>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep, (const int64_t*)h->d_blk_total);
+    else hipLaunchKernelGGL(k_pivot<false>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep, (const int64_t*)h->d_blk_total);
 }
 
 void launch_apply(mcf_handle* h, hipStream_t s) {
@@ -1197,7 +1226,7 @@ void free_all(mcf_handle* h) {
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
-    (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept);
+    (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_blk_tab); (void)hipFree(h->d_blk_total);
     (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
     if (h->h_one) (void)hipHostFree(h->h_one);
@@ -1599,9 +1628,9 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
         const int64_t z = 0, one = 1;
         if (h->rcached) {
             if (rule == MCF_RULE_DEVEX_BLOCK)
-                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, true, false>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux, (int64_t*)nullptr);
+                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, true, false>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux, (int64_t*)nullptr, (const int32_t*)nullptr);
             else
-                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, true, false>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux, (int64_t*)nullptr);
+                hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, true, false>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux, (int64_t*)nullptr, (const int32_t*)nullptr);
         } else {
             if (rule == MCF_RULE_DEVEX_BLOCK)
                 hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, true>), grid, block, 0, h->stream, v, z, one, 0, start, end, h->d_cand_aux);
