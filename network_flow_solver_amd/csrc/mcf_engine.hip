@@ -238,7 +238,9 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
     const bool early = use_block != 1;  // full sweep: the slice is known without the control block
     int64_t g0 = 0;
     if (early) {
-        mcf_bucket_slice(v.bucket_off, x, shard, shards, 0, 1, &lo, &hi);
+        // this rank's share of bucket x: a host-made table when the arc list is sharded (divisions otherwise)
+        if (blk_tab) { lo = blk_tab[x * 2]; hi = blk_tab[x * 2 + 1]; }
+        else mcf_bucket_slice(v.bucket_off, x, shard, shards, 0, 1, &lo, &hi);
         g_lo = lo >> 2; g_hi = (hi + 3) >> 2;  // groups of 4 arcs
         g0 = g_lo + lb * kPriceThreads + threadIdx.x;
         if (g0 < g_hi) load_batch(g0);
@@ -986,6 +988,7 @@ struct mcf_handle {
     int64_t* d_swept = nullptr;  // arcs swept per pricing workgroup (summed by mcf_get_result)
     int32_t* d_blk_tab = nullptr;  // Devex: (lo, hi) of this rank's share of block k of bucket x, [num_blocks][8][2]
     int64_t* d_blk_total = nullptr;  // Devex: arcs of block k over all shards (accounting)
+    int32_t* d_full_tab = nullptr;   // sharded full sweeps: (lo, hi) of this rank's share of bucket x, [8][2]
     bool rcached = false;     // large instance: resident reduced costs + k_rcupd
     int rcupd_blocks = 1;
     McfSeg* d_seg = nullptr;
@@ -1074,6 +1077,16 @@ int upload_image(mcf_handle* h) {
     c.minor_cap = mcf_minor_cap(h->price_blocks);
     c.climb_budget = h->climb_budget;
     *h->h_ctx = c;
+    if (h->shards > 1 && !h->d_full_tab) {
+        int32_t tab[MCF_NUM_BUCKETS * 2];
+        for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+            int64_t lo, hi;
+            mcf_bucket_slice(im.bucket_off, x, h->shard, h->shards, 0, 1, &lo, &hi);
+            tab[x * 2] = (int32_t)lo; tab[x * 2 + 1] = (int32_t)hi;
+        }
+        if (dalloc(&h->d_full_tab, MCF_NUM_BUCKETS * 2) != hipSuccess) { h->err = "hipMalloc slice table"; return MCF_E_ALLOC; }
+        HIP_TRY(h, hipMemcpy(h->d_full_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+    }
     if (h->opt.rule == MCF_RULE_DEVEX_BLOCK && c.num_blocks <= 4096 && !h->d_blk_tab) {  // block bounds, once
         std::vector<int32_t> tab((size_t)c.num_blocks * MCF_NUM_BUCKETS * 2);
         for (int64_t k = 0; k < c.num_blocks; ++k)
@@ -1124,8 +1137,8 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
         if (rule == MCF_RULE_DEVEX_BLOCK)
             hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, use_block == 1 ? h->d_blk_tab : nullptr);
         else
-            if (v.dirty) hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, true>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)nullptr);
-            else hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)nullptr);
+            if (v.dirty) hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, true>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)h->d_full_tab);
+            else hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)h->d_full_tab);
     } else {
         if (rule == MCF_RULE_DEVEX_BLOCK)
             hipLaunchKernelGGL((k_price<MCF_RULE_DEVEX_BLOCK, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out);
@@ -1226,7 +1239,7 @@ void free_all(mcf_handle* h) {
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
-    (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_blk_tab); (void)hipFree(h->d_blk_total);
+    (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_blk_tab); (void)hipFree(h->d_blk_total); (void)hipFree(h->d_full_tab);
     (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
     if (h->h_one) (void)hipHostFree(h->h_one);

@@ -207,6 +207,67 @@ def test_cycle_scan_above_65535_nodes(gpu_engine_module):
     check_tree_invariants(inst.n, tb["parent"], tb["size"], tb["pos"], tb["order"], tb["depth"], tb["psize"])
 
 
+@pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
+@pytest.mark.parametrize("full_sweeps", [1, -1], ids=["full_sweeps", "incremental_sweeps"])
+def test_sharded_kernels_on_one_gpu(gpu_engine_module, rule, full_sweeps):
+    """The arc-sharded multi-GPU kernels on real hardware without RCCL: three handles on this GPU, each pricing its
+    third of every bucket (options.shard_rank / shard_count); per pivot mcf_enqueue_price on each, the three 16-byte
+    candidates put side by side (what the all-gather does), mcf_enqueue_pivot on each.  The replicas must stay
+    bit-identical, and -- Dantzig / Devex -- pivot exactly like the unsharded engine."""
+    import ctypes
+
+    e = gpu_engine_module
+    inst = generators.named_instance("netgen_8_10a")
+    G = 3
+    engs = [e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, shard=(r, G), device=0,
+                        full_sweeps=full_sweeps) for r in range(G)]
+    # plain HIP for the candidate buffers (the runtime libmcf_hip.so already loaded; torch's own copy of it cannot be
+    # initialised in the same process afterwards)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), 32 * G) == 0 and hip.hipMemset(buf, 0, 32 * G) == 0
+    local = [buf.value + 16 * r for r in range(G)]          # one 16-byte candidate per rank ...
+    gathered = buf.value + 16 * G                            # ... and the gathered list
+    try:
+        for eng in engs:
+            eng.set_max_pivots(10 ** 9)
+        done = False
+        for _batch in range(4000):
+            for _ in range(32):
+                for r, eng in enumerate(engs):
+                    eng.enqueue_price(0, local[r])
+                assert hip.hipMemcpyAsync(gathered, buf.value, 16 * G, 3, None) == 0   # device to device, null stream
+                for eng in engs:
+                    eng.enqueue_pivot(0, gathered, G)
+            assert hip.hipDeviceSynchronize() == 0
+            polls = [eng.poll() for eng in engs]
+            assert len(set(polls)) == 1                      # same status, same pivot count on every replica
+            if polls[0][0] is not None:
+                done = True
+                break
+        assert done
+        results = [(eng.result(), eng.tree()) for eng in engs]
+    finally:
+        for eng in engs:
+            eng.close()
+        hip.hipFree(buf)
+    r0, t0 = results[0]
+    assert r0.status == "optimal"
+    for r, t in results[1:]:
+        assert np.array_equal(r.flow, r0.flow) and np.array_equal(r.potential, r0.potential)
+        assert np.array_equal(t["order"], t0["order"]) and np.array_equal(t["parent"], t0["parent"])
+    single, ts = _solve(e, inst, rule, fused=False, mid_loop=-1)
+    assert single.objective == r0.objective
+    check_optimality(inst, r0.flow, r0.potential)
+    if rule != 2:   # candidate list: sharded, the list holds one entry per rank instead of one per pricing workgroup
+        assert single.stats["pivots"] == r0.stats["pivots"]
+        assert np.array_equal(single.flow, r0.flow) and np.array_equal(ts["order"], t0["order"])
+
+
 def _chain_instance(n, skip=7):
     """A path 0 -> 1 -> ... -> n-1 with capacity 10, shortcut arcs every `skip` nodes and one expensive direct
     arc; 15 units from 0 to n-1.  The optimal tree is essentially the path: cycles thousands of arcs long (the
