@@ -76,7 +76,7 @@ class Mi355xAdapter:
             elapsed_ms = (time.perf_counter() - start) * 1e3
             return SolverResult(cls.name, "", result.status, result.objective if result.status == "optimal" else None,
                                 elapsed_ms, result.iterations,
-                                metadata={"pricing_strategy": "block-search Devex (auto: Dantzig on grid-on-torus)",
+                                metadata={"pricing_strategy": f"{SolverOptions().pricing_strategy} (auto: Dantzig on grid-on-torus)",
                                           "has_duals": True, "device": "MI355X (gfx950)"})
         except Exception as exc:  # adapters never raise (base.py:52-54)
             return SolverResult(cls.name, "", "error", None, 0.0, None, error_message=f"{type(exc).__name__}: {exc}")
