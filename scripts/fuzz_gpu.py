@@ -20,12 +20,12 @@ while time.time() < t_end and runs < max_runs:
     rng = random.Random(seed)
     fam = rng.choice(["netgen", "gridgen", "goto"])
     if fam == "netgen":
-        n = rng.choice([40, 130, 300, 700, 1500, 3000, 6000])
+        n = rng.choice([40, 130, 300, 700, 1500, 3000, 6000, 12000, 20000])
         inst = generators.netgen_style(n, n * rng.choice([4, 8, 12]), seed=seed)
     elif fam == "gridgen":
-        w = rng.choice([6, 12, 20, 33, 50, 70]); inst = generators.gridgen_style(w, rng.choice([w, w + 3]), seed=seed)
+        w = rng.choice([6, 12, 20, 33, 50, 70, 110]); inst = generators.gridgen_style(w, rng.choice([w, w + 3]), seed=seed)
     else:
-        w = rng.choice([6, 12, 20, 33, 50, 70]); inst = generators.goto_style(w, w, seed=seed)
+        w = rng.choice([6, 12, 20, 33, 50, 70, 110]); inst = generators.goto_style(w, w, seed=seed)
     rule = rng.choice([0, 1, 2])
     opts = dict(fused=rng.random() < 0.5, mid_loop=rng.choice([-1, 0, 1]), cycle_scan=rng.choice([-1, 0, 0, 1, 3]),
                 full_sweeps=rng.choice([-1, 0, 1]), use_graph=rng.random() < 0.7, batch_pivots=rng.choice([7, 32, 64]))
