@@ -297,6 +297,22 @@ def _load_emul():
     return _emul
 
 
+def emul_check_block_map(inst, price_blocks: int, shard: int = 0, shards: int = 1) -> int:
+    """Arcs on which mcf_price_block_of (incremental pricing's arc -> pricing-workgroup map) disagrees with the
+    sweep's loop structure; 0 = consistent."""
+    lib = _load_emul()
+    i32p, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+    lib.emul_check_block_map.argtypes = [ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, ctypes.c_int32,
+                                         ctypes.c_int64, ctypes.c_int64]
+    lib.emul_check_block_map.restype = ctypes.c_int64
+    tail = np.ascontiguousarray(inst.tail, np.int32); head = np.ascontiguousarray(inst.head, np.int32)
+    cost = np.ascontiguousarray(inst.cost, np.int64); cap = np.ascontiguousarray(inst.cap, np.int64)
+    supply = np.ascontiguousarray(inst.supply, np.int64)
+    return int(lib.emul_check_block_map(inst.n, len(tail), _ptr(tail, ctypes.c_int32), _ptr(head, ctypes.c_int32),
+                                        _ptr(cost, ctypes.c_int64), _ptr(cap, ctypes.c_int64), _ptr(supply, ctypes.c_int64),
+                                        price_blocks, shard, shards))
+
+
 def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0, max_pivots: int = -1,
                trace: int = 0, bucketed: bool = True, climb_budget: int = -1,
                warm_in_tree=None, warm_at_upper=None) -> dict:

@@ -289,4 +289,40 @@ void emul_poll(void* h, int32_t* status, int64_t* pivots, int64_t* objective_hi_
 
 void emul_destroy(void* h) { delete static_cast<Emul*>(h); }
 
+// Incremental pricing: the arc -> pricing-workgroup map the marking passes use (mcf_price_block_of) against the
+// sweep's own loop structure (k_price_rc: workgroup lb * 8 + x takes the groups g_lo + lb * 256 + lane + j * nlb * 256
+// of this rank's share of bucket x).  Returns the number of arcs on which the two disagree (0 = consistent);
+// arcs of other ranks must map to -1.
+int64_t emul_check_block_map(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, const int64_t* cost,
+                             const int64_t* cap, const int64_t* supply, int32_t price_blocks, int64_t shard, int64_t shards) {
+    Emul e;
+    int err = 0;
+    std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e.im, &err, true);
+    if (err) return -1;
+    bind(e);
+    McfDirty d;
+    std::memset(&d, 0, sizeof d);
+    d.nlb = price_blocks / MCF_NUM_BUCKETS;
+    for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+        int64_t lo, hi;
+        mcf_bucket_slice(e.im.bucket_off, x, shard, shards, 0, 1, &lo, &hi);
+        d.lo[x] = (int32_t)lo; d.hi[x] = (int32_t)hi;
+    }
+    std::vector<int32_t> truth(m, -1);
+    const int64_t nlb = d.nlb;
+    for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+        const int64_t lo = d.lo[x], hi = d.hi[x], g_lo = lo >> 2, g_hi = (hi + 3) >> 2;
+        for (int64_t lb = 0; lb < nlb; ++lb)
+            for (int64_t g0 = g_lo + lb * 256; g0 < g_hi; g0 += nlb * 256)
+                for (int64_t g = g0; g < g0 + 256 && g < g_hi; ++g)
+                    for (int k = 0; k < 4; ++k) {
+                        const int64_t i = (g << 2) + k;
+                        if (i >= lo && i < hi) truth[i] = (int32_t)(lb * MCF_NUM_BUCKETS + x);
+                    }
+    }
+    int64_t bad = 0;
+    for (int64_t i = 0; i < m; ++i) bad += mcf_price_block_of(e.view, &d, i) != truth[i];
+    return bad;
+}
+
 }  // extern "C"

@@ -172,3 +172,14 @@ def test_cycle_scan_above_65535_nodes():
         assert np.array_equal(a[key], b[key]), key
     assert b["psize"][0] == inst.n + 1 > 65535
     check_tree_invariants(inst.n, b["parent"], b["size"], b["pos"], b["order"], b["depth"], b["psize"])
+
+
+@pytest.mark.parametrize("price_blocks", [8, 24, 64, 2048])
+@pytest.mark.parametrize("shard,shards", [(0, 1), (0, 3), (2, 3), (5, 8)])
+def test_incremental_pricing_block_map_matches_the_sweep(price_blocks, shard, shards):
+    """The passes that change an arc flag the pricing workgroup that sweeps it (mcf_price_block_of); the map must be
+    the sweep's own lane -> arc assignment, for any grid size and any shard, and -1 for other ranks' arcs."""
+    from network_flow_solver_amd import generators
+    for inst in (generators.netgen_style(300, 2400, seed=5), generators.netgen_style(5000, 70001, seed=6),
+                 generators.goto_style(40, 40, seed=7)):
+        assert oracle.emul_check_block_map(inst, price_blocks, shard, shards) == 0
