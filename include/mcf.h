@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MCF_ABI_VERSION 1
+#define MCF_ABI_VERSION 2
 
 /* return codes */
 #define MCF_OK 0
@@ -59,7 +59,8 @@ extern "C" {
 /* pricing rules */
 #define MCF_RULE_DANTZIG_FULL 0   /* full-scan most-violating arc (simplex_pricing.py:97-137) */
 #define MCF_RULE_DEVEX_BLOCK 1    /* round-robin block search, merit rc^2/w, deferred weight update
-                                     (simplex_pricing.py:310-357, 271-292) */
+                                     (simplex_pricing.py:310-357, 271-292), block-size tuner (simplex_adaptive.py:98-151),
+                                     weights reset every 64 basis swaps (simplex.py:1370-1400) */
 #define MCF_RULE_CANDIDATE_LIST 2 /* full Dantzig sweep keeps one candidate per pricing workgroup; the following
                                      pivots re-price only that list (simplex_pricing.py:375-542, 419-456) */
 
@@ -87,6 +88,11 @@ typedef struct mcf_options {
                                 0 = auto (by size and rule), -1 = never, 1 = whenever the handle allows it */
     int32_t full_sweeps;     /* incremental Dantzig / candidate-list sweeps (a pricing workgroup whose arcs have not changed since
                                 it last swept them keeps its candidate): 0 = auto (from 4 M arcs), 1 = never, -1 = always */
+    int32_t devex_tuner;     /* Devex block-size tuner (simplex_adaptive.py:98-151): 0 = auto (on when block_size is 0, as in the
+                                reference; off for a caller-given block size), 1 = on, -1 = off */
+    int32_t devex_stay;      /* Devex block advance: 0 = cyclic (next block after every pivot), 1 = stay on a block until it holds
+                                no eligible arc (the reference's loop, simplex_pricing.py:325-355; needs the tuner to converge) */
+    int32_t reserved[4];     /* must be 0 */
 } mcf_options;
 
 typedef struct mcf_stats {
@@ -192,6 +198,11 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
  * when the handle keeps one (*resident = 1), else cost + pi[tail] - pi[head] computed on the host.
  * Tests use it to check the invariant resident rc == cost + pi[tail] - pi[head]. */
 int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident);
+
+/* Devex reference weights of every arc (caller's order; 1.0 for a handle that never priced with the Devex rule).
+ * With mcf_get_tree / mcf_get_result this is the full input of one block selection, so that a test can replay
+ * mcf_price_once(MCF_RULE_DEVEX_BLOCK, ...) on the oracle's restated _select_entering_arc_vectorized. */
+int mcf_get_weights(mcf_handle* h, float* weight_out);
 
 /* ---- native DIMACS "p min" reader (host only; replaces benchmarks/parsers/dimacs.py:105-286 for
  * instances too large for one Python object per arc).  Two calls: mcf_dimacs_scan returns the

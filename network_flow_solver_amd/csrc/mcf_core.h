@@ -139,6 +139,24 @@ struct alignas(16) McfCand {
 
 #define MCF_NUM_BUCKETS 8  // one head-node bucket per XCD (8 XCDs, private 4 MiB L2 each)
 
+// ---- Devex block search (simplex_pricing.py:310-357) with the reference's block-size tuner
+// (simplex_adaptive.py:98-151) and its periodic weight reset (simplex.py:1370-1400, every 64 basis swaps).
+// A block is a run of `block_granules` consecutive GRANULES; granule g is the g-th 1/64 of every head bucket
+// (so a block spans all 8 XCDs and a block of 64 granules is the whole arc list).  The tuner moves the block
+// size in granule units: x1.5 when more than 30 % of the last >= 50 pivots were degenerate, x0.75 below 10 %.
+// Measured on the reference itself (oracle with the tuner / the reset switched off): both are essential --
+// netgen_8_12a takes 10 113 pivots with both, 34 757 without the reset and does not finish without the tuner.
+#define MCF_GRANULES 64
+#define MCF_WLIST_CAP 1024       // arcs whose weight differs from 1 between two resets (overflow forces a reset)
+#define MCF_DEVEX_RESET_SWAPS 64 // ft_update_limit (data.py / simplex.py:1370-1373)
+#define MCF_TUNER_MAX_ARCS 16384  // largest block the tuner grows to (= what one persistent workgroup prices per pivot)
+#define MCF_DIR_FLAG (1 << 30)   // Devex tie rule: bit 30 of the caller's arc index word marks a FORWARD candidate
+struct McfDevex {
+    int32_t gran[MCF_NUM_BUCKETS][MCF_GRANULES + 1];  // engine arc index where granule g of bucket x starts
+    int32_t gtot[MCF_GRANULES + 1];                   // sum over the buckets of gran[x][g] (arcs before granule g; accounting)
+    int32_t wlist[MCF_WLIST_CAP];                     // engine arcs whose weight was set since the last reset
+};
+
 // Segment of the block permutation that re-roots the moved subtree:
 // new positions [dst, dst+len) take old positions [src, src+len).
 struct McfSeg {
@@ -159,11 +177,21 @@ struct McfCtx {
     int64_t nodes_moved;       // sum of preorder positions rewritten (diagnostic)
     int64_t subtree_nodes;     // sum of |T2| (diagnostic)
     int64_t cycle_arcs;        // sum of cycle lengths (diagnostic)
-    // ---- block-search state (Devex rule): block k = slice k of every bucket
+    // ---- block-search state (Devex rule): block k = granules [k * block_granules, (k + 1) * block_granules) of every bucket
     int64_t block_size;        // nominal arcs per block (reporting only)
     int64_t block_index;       // block the next pricing pass scans
     int32_t empty_blocks;      // consecutive blocks without a candidate
-    int32_t num_blocks;
+    int32_t num_blocks;        // ceil(MCF_GRANULES / block_granules)
+    int32_t block_granules;    // 1 .. MCF_GRANULES
+    int32_t auto_tune;         // 1: the tuner below adapts block_granules (block_size "auto", simplex_adaptive.py:70-96)
+    int32_t tn_total, tn_degenerate;  // pivots / degenerate pivots since the last adaptation (record_pivot)
+    int64_t tn_last_adapt;     // pivot count at the last adaptation
+    int32_t swaps_since_reset; // basis swaps since the Devex weights were last reset
+    int32_t wlist_n;           // entries of McfDevex::wlist in use
+    int32_t wreset;            // hand-over decide -> finish: reset the listed weights to 1
+    int32_t devex_cyclic;      // 1: the block advances after every pivot; 0: stay on a block until it is empty (the reference)
+    int32_t max_granules;      // the tuner never grows a block beyond this (bounds the arcs one pricing pass reads)
+    int32_t pad1;
     // ---- candidate-list state
     int32_t minor_left;        // > 0: the next pass re-prices the candidate list instead of sweeping
     int32_t minor_cap;         // minor pivots allowed per full sweep
@@ -213,6 +241,7 @@ struct McfView {
     int64_t bucket_off[MCF_NUM_BUCKETS + 1];  // engine arcs of bucket x: [bucket_off[x], bucket_off[x+1])
     int8_t* state;          // [m_pad]  +1 at lower bound, -1 at upper bound, 0 basic / padding
     float* weight;          // [m_pad]  Devex reference weights (nullptr for Dantzig)
+    McfDevex* dx;           // Devex granule table + list of touched weights (nullptr for the other rules)
     McfArcW* arcw;          // [m + n_nodes - 1]
     int64_t* pi;            // [n_nodes]
     McfNode* node;          // [n_nodes]
@@ -295,6 +324,80 @@ MCF_HD void mcf_bucket_slice(const int64_t* bucket_off, int x, int64_t r, int64_
     *hi = a + len2 * (r + 1) / G;
 }
 
+// Devex: the arcs of block `k` (of `bg` granules each) inside bucket x, and of those the rank's share r of G.
+MCF_HD void mcf_devex_slice(const McfDevex* dx, int x, int64_t r, int64_t G, int32_t k, int32_t bg, int64_t* lo, int64_t* hi) {
+    int32_t g0 = k * bg;
+    if (g0 >= MCF_GRANULES) g0 = 0;  // (simplex_pricing.py:329-331: wrap to the first block)
+    const int32_t g1 = g0 + bg < MCF_GRANULES ? g0 + bg : MCF_GRANULES;
+    const int64_t a = dx->gran[x][g0], b = dx->gran[x][g1];
+    if (G == 1) { *lo = a; *hi = b; return; }
+    const int64_t len = b - a;
+    *lo = a + len * r / G;
+    *hi = a + len * (r + 1) / G;
+}
+// host-side fill of the granule table
+MCF_HD void mcf_devex_fill_granules(McfDevex* dx, const int64_t* bucket_off) {
+    for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+        const int64_t s0 = bucket_off[x], len = bucket_off[x + 1] - s0;
+        for (int g = 0; g <= MCF_GRANULES; ++g) dx->gran[x][g] = (int32_t)(s0 + len * g / MCF_GRANULES);
+    }
+    for (int g = 0; g <= MCF_GRANULES; ++g) {
+        int64_t t = 0;
+        for (int x = 0; x < MCF_NUM_BUCKETS; ++x) t += dx->gran[x][g] - bucket_off[x];
+        dx->gtot[g] = (int32_t)t;
+    }
+}
+// arcs of block k (all buckets, all shards)
+MCF_HD int64_t mcf_devex_block_arcs(const McfDevex* dx, int32_t k, int32_t bg) {
+    int32_t g0 = k * bg;
+    if (g0 >= MCF_GRANULES) g0 = 0;
+    const int32_t g1 = g0 + bg < MCF_GRANULES ? g0 + bg : MCF_GRANULES;
+    return (int64_t)dx->gtot[g1] - dx->gtot[g0];
+}
+// block size in granules for a nominal block of `bs` arcs out of m
+MCF_HD int32_t mcf_devex_granules_for(int64_t bs, int64_t m) {
+    if (m <= 0) return MCF_GRANULES;
+    int64_t g = (bs * MCF_GRANULES + m / 2) / m;
+    if (g < 1) g = 1;
+    if (g > MCF_GRANULES) g = MCF_GRANULES;
+    return (int32_t)g;
+}
+// Block-search state of a fresh solve: the reference's initial block size m/4, m/8, m/16 (simplex_adaptive.py:89-96)
+// in granule units with the tuner on, or the caller's fixed block size with the tuner off (data.py: block_size int).
+MCF_HD void mcf_init_block_state(McfCtx* c, int32_t rule, int64_t m, int64_t block_size) {
+    c->auto_tune = 0;
+    c->block_granules = MCF_GRANULES;
+    c->num_blocks = 1;
+    c->block_size = m > 0 ? m : 1;
+    c->block_index = 0;
+    c->empty_blocks = 0;
+    c->tn_total = 0; c->tn_degenerate = 0; c->tn_last_adapt = 0;
+    c->swaps_since_reset = 0; c->wlist_n = 0; c->wreset = 0;
+    c->devex_cyclic = 1;
+    c->max_granules = MCF_GRANULES;
+    if (rule != MCF_RULE_DEVEX_BLOCK) return;
+    int64_t bs = block_size;
+    if (bs <= 0) {
+        c->auto_tune = 1;
+        bs = m < 1000 ? m / 4 : (m < 10000 ? m / 8 : m / 16);
+    }
+    if (bs < 1) bs = 1;
+    c->block_granules = mcf_devex_granules_for(bs, m);
+    c->num_blocks = (MCF_GRANULES + c->block_granules - 1) / c->block_granules;
+    c->block_size = m * c->block_granules / MCF_GRANULES > 0 ? m * c->block_granules / MCF_GRANULES : 1;
+    // the tuner may grow a block up to MCF_TUNER_MAX_ARCS arcs (never below the initial size): beyond that a
+    // pricing pass stops being a latency-bound hop and starts to cost bandwidth, while the pivot count no longer
+    // improves (measured: netgen_8_14a 41 826 pivots with whole-list blocks, 42 571 with m/16 blocks)
+    int32_t cap = m > 0 ? (int32_t)((int64_t)MCF_TUNER_MAX_ARCS * MCF_GRANULES / m) : MCF_GRANULES;
+    if (cap > MCF_GRANULES) cap = MCF_GRANULES;
+    c->max_granules = cap > c->block_granules ? cap : c->block_granules;
+}
+
+// Devex candidates carry their direction in the id word: among equal merits the reference's vectorised selection
+// prefers a BACKWARD arc (forward wins only when strictly greater, simplex.py:596), then the lowest index
+// (np.argmax).  state > 0 = forward.
+MCF_HD int32_t mcf_devex_tie_id(int32_t orig, int32_t state) { return state > 0 ? (orig | MCF_DIR_FLAG) : orig; }
+
 // Reduced cost of arc i under the current potentials (simplex.py:508-512):
 // rc = cost + pi[tail] - pi[head].  An arc is eligible when state * rc < 0
 // (simplex_pricing.py:124-131 with residuals expressed through `state`).
@@ -373,6 +476,7 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
     McfCtx* c = v.ctx;
     c->apply = 0;
     c->stage = 0;
+    if (c->wreset) { c->wreset = 0; c->wlist_n = 0; }  // the previous finish pass reset the listed Devex weights
     if (c->pending_flip) {  // the previous apply pass wrote order[cur ^ 1]
         c->cur ^= 1;
         c->prev_lo = c->lo;
@@ -403,15 +507,14 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
         if (minor) { c->minor_left -= 1; c->minor_pivots += 1; }
         else c->minor_left = c->minor_cap;
     }
-    if (rule == MCF_RULE_DEVEX_BLOCK) {
-        // Cyclic partial pricing: the next pass looks at the NEXT block whether or not this one had a
-        // candidate.  The reference stays on a block until it is exhausted (simplex_pricing.py:325-355);
-        // measured on the netgen/gridgen/goto goldens that costs 2-2.7x more pivots for the same optimum
-        // (e.g. 54 600 vs 24 486 on netgen_8_12a), so the engine does not mirror it.
+    if (rule == MCF_RULE_DEVEX_BLOCK && c->devex_cyclic) {
+        // cyclic variant: the next pass looks at the NEXT block whether or not this one had a candidate
+        // (the reference stays on a block until it is exhausted, simplex_pricing.py:325-355)
         c->block_index += 1;
         if (c->block_index >= c->num_blocks) c->block_index = 0;
     }
 
+    if (rule == MCF_RULE_DEVEX_BLOCK && c->block_index >= c->num_blocks) c->block_index = 0;  // (a tuner step may have shrunk num_blocks)
     const int32_t e = (int32_t)(best_arc & 0xffffffff);  // engine index (low word of the packed id)
     const int32_t s = v.state[e];  // +1: flow rises from 0; -1: flow falls from cap
     const int32_t first = s > 0 ? v.tail[e] : v.head[e];
@@ -714,10 +817,49 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycl
     c->pivots += 1;
     c->cycle_arcs += n1 + n2 + 1;
     c->pv_e = e; c->pv_s = s; c->pv_n1 = n1; c->pv_n2 = n2; c->pv_delta = delta; c->pv_result = result;
-    if (v.weight) {  // Devex: only the selected arc's weight is refreshed (simplex_pricing.py:271-292);
-        // ||B^-1 a||^2 of a tree basis = number of tree arcs between the end points
-        const int32_t len = n1 + n2;
-        v.weight[e] = (float)(len > 0 ? len : 1);
+    if (v.weight) {
+        // Devex bookkeeping, all of it scalar (lane 0).
+        // (1) periodic reset (simplex.py:1370-1400: after ft_update_limit = 64 rank-one updates the basis is
+        //     refactorised and the pricing strategy reset: weights 1, block 0).  Only basis swaps count.
+        bool reset = false;
+        if (result != 0) {
+            if (c->swaps_since_reset >= MCF_DEVEX_RESET_SWAPS) { reset = true; c->swaps_since_reset = 0; }
+            else c->swaps_since_reset += 1;
+        }
+        // (2) deferred weight update: only the selected arc's weight is refreshed (simplex_pricing.py:271-292);
+        //     ||B^-1 a||^2 of a tree basis = number of tree arcs between the end points.  The touched arcs are
+        //     listed so that a reset costs a pass over the list instead of over all arcs.
+        if (!reset && v.dx) {
+            if (c->wlist_n >= MCF_WLIST_CAP) reset = true;  // list full: reset early (heuristic state only)
+            else {
+                const int32_t len = n1 + n2;
+                v.weight[e] = (float)(len > 0 ? len : 1);
+                v.dx->wlist[c->wlist_n] = e;
+                c->wlist_n += 1;
+            }
+        }
+        if (reset) { c->wreset = 1; c->block_index = 0; }
+        // (3) block-size tuner (simplex_adaptive.py:98-151): every >= 50 pivots, on the share of degenerate pivots
+        //     (record_pivot counts theta == 0 and entering == leaving, simplex.py:1316-1318)
+        c->tn_total += 1;
+        if (delta == 0 || result == 0) c->tn_degenerate += 1;
+        if (c->auto_tune && c->pivots - c->tn_last_adapt >= 50 && c->tn_total >= 10) {
+            int32_t bg = c->block_granules;
+            if (10 * c->tn_degenerate > 3 * c->tn_total) {         // > 30 % degenerate: larger blocks
+                const int32_t nb = bg * 3 / 2 > bg + 1 ? bg * 3 / 2 : bg + 1;
+                bg = nb < c->max_granules ? nb : (bg > c->max_granules ? bg : c->max_granules);
+            } else if (10 * c->tn_degenerate < c->tn_total) {      // < 10 %: smaller blocks
+                const int32_t nb = bg * 3 / 4;
+                bg = nb > 1 ? nb : 1;
+            }
+            if (bg != c->block_granules) {
+                c->block_granules = bg;
+                c->num_blocks = (MCF_GRANULES + bg - 1) / bg;
+                c->block_size = v.m * bg / MCF_GRANULES;
+                if (c->block_index >= c->num_blocks) c->block_index = 0;
+            }
+            c->tn_degenerate = 0; c->tn_total = 0; c->tn_last_adapt = c->pivots;
+        }
     }
     if (result == 0) {  // entering arc is also the leaving arc (simplex.py:1320-1334)
         c->bound_flips += 1;
@@ -792,6 +934,10 @@ MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane,
     if (stage == 0) return;
     const int32_t e = c->pv_e, s = c->pv_s, n1 = c->pv_n1, n2 = c->pv_n2;
     const int64_t delta = c->pv_delta;
+    if (c->wreset && v.dx) {  // Devex weight reset: the touched arcs go back to 1 (the caller clears wreset / wlist_n afterwards)
+        const int32_t nw = c->wlist_n;
+        for (int32_t i = lane; i < nw; i += nlanes) v.weight[v.dx->wlist[i]] = 1.0f;
+    }
 
     // --- flow update along the cycle (simplex.py:1255-1283): distinct arcs, one per lane
     if (delta > 0) {

@@ -47,7 +47,7 @@ constexpr int kPriceThreads = 256;
 constexpr int kPivotThreads = 1024;  // one workgroup: final arg-max, cycle search (climb by one lane / scan by all), finish
 constexpr int kReduceThreads = 256;
 constexpr int kMidMaxNodes = 1 << 13;        // persistent single-workgroup loop (k_solve_mid): auto up to this many nodes ...
-constexpr int kMidMaxArcsPerPivot = 1 << 14;  // ... and this many arcs priced inside the loop per pivot
+constexpr int kMidMaxArcsPerPivot = MCF_TUNER_MAX_ARCS + 1024;  // ... and this many arcs priced inside the loop per pivot
 constexpr int64_t kIncrementalMinArcs = (int64_t)1 << 22;  // incremental sweeps by default from this many arcs
 constexpr int kScanMaxNodes = 1 << 20;  // beyond this the position-space sizes are not kept: the cycle is always climbed
 constexpr int kApplyThreads = 256;
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shar
         const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
         const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
         int64_t lo, hi;
-        mcf_bucket_slice(v.bucket_off, x, shard, shards, use_block == 1 ? c->block_index : 0,
-                         use_block == 1 ? c->num_blocks : 1, &lo, &hi);
+        if (use_block == 1 && v.dx) mcf_devex_slice(v.dx, x, shard, shards, (int32_t)c->block_index, c->block_granules, &lo, &hi);
+        else mcf_bucket_slice(v.bucket_off, x, shard, shards, 0, 1, &lo, &hi);
         const int64_t g_lo = lo >> 2, g_hi = (hi + 3) >> 2;  // groups of 4 arcs
         const int4* __restrict__ tail4 = reinterpret_cast<const int4*>(v.tail);
         const int4* __restrict__ head4 = reinterpret_cast<const int4*>(v.head);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shar
                     if (kk < key) continue;              // cannot win: skip the id lookup
                     const int32_t o = orig[i];
                     if (FILTER && (o < f_lo || o >= f_hi)) continue;
-                    const int64_t id = mcf_pack_arc(o, i);
+                    const int64_t id = mcf_pack_arc(RULE == MCF_RULE_DEVEX_BLOCK ? mcf_devex_tie_id(o, s) : o, i);
                     if (mcf_cand_better(kk, id, key, arc)) { key = kk; arc = id; }
                 }
             }
@@ -254,12 +254,13 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
     if (INC && v.dirty && use_block != 1 && (c->status != MCF_RUNNING || !v.dirty->flag[blockIdx.x])) return;
     int64_t key = 0, arc = -1;
     int64_t best_i = -1;  // engine index of this lane's best arc (its caller's id is looked up at the end)
+    int32_t best_s = 0;   // its state (Devex: the direction takes part in the tie rule)
     if (c->status == MCF_RUNNING) {
         if (!early) {
-            // Devex block search: this rank's share of block k of bucket x -- tabulated by the host (four emulated
-            // 64-bit divisions otherwise, ~0.8 us on this kernel's critical path)
-            if (blk_tab) { const int64_t k = c->block_index; lo = blk_tab[(k * MCF_NUM_BUCKETS + x) * 2]; hi = blk_tab[(k * MCF_NUM_BUCKETS + x) * 2 + 1]; }
-            else mcf_bucket_slice(v.bucket_off, x, shard, shards, c->block_index, c->num_blocks, &lo, &hi);
+            // Devex block search: this rank's share of block k of bucket x, from the host-made granule table (two
+            // dependent 4-byte loads; the block size changes under the tuner, so blocks themselves cannot be tabulated)
+            if (v.dx) mcf_devex_slice(v.dx, x, shard, shards, (int32_t)c->block_index, c->block_granules, &lo, &hi);
+            else mcf_bucket_slice(v.bucket_off, x, shard, shards, 0, 1, &lo, &hi);
             g_lo = lo >> 2; g_hi = (hi + 3) >> 2;
             g0 = g_lo + lb * kPriceThreads + threadIdx.x;
             if (g0 < g_hi) load_batch(g0);
@@ -296,14 +297,19 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
                         const int32_t o = orig[i];
                         if (o < f_lo || o >= f_hi) continue;
                     }
-                    if (kk > key) { key = kk; best_i = i; }
-                    else if (best_i < 0 || orig[i] < orig[best_i]) best_i = i;  // tie on the key (rare): lowest caller's index
+                    if (kk > key) { key = kk; best_i = i; best_s = s; }
+                    else if (best_i < 0) { best_i = i; best_s = s; }
+                    else {  // tie on the key (rare): Devex prefers a backward arc, then the lowest caller's index
+                        const int32_t a = RULE == MCF_RULE_DEVEX_BLOCK ? mcf_devex_tie_id(orig[i], s) : orig[i];
+                        const int32_t b = RULE == MCF_RULE_DEVEX_BLOCK ? mcf_devex_tie_id(orig[best_i], best_s) : orig[best_i];
+                        if (a < b) { best_i = i; best_s = s; }
+                    }
                 }
             }
             g0 += stride * U;
             if (g0 < g_hi) load_batch(g0);
         }
-        if (best_i >= 0) arc = mcf_pack_arc(orig[best_i], best_i);
+        if (best_i >= 0) arc = mcf_pack_arc(RULE == MCF_RULE_DEVEX_BLOCK ? mcf_devex_tie_id(orig[best_i], best_s) : orig[best_i], best_i);
     }
     block_argmax<kPriceThreads>(key, arc);
     if (threadIdx.x == 0) {
@@ -447,20 +453,9 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
     MCF_PSTAMP(9);
 }
 
-// arcs one Devex pass looks at (all shards): block k of every bucket
-__device__ __forceinline__ int64_t devex_block_arcs(const McfView& v, const McfCtx& c) {
-    int64_t priced = 0;
-    for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
-        int64_t lo, hi;
-        mcf_bucket_slice(v.bucket_off, x, 0, 1, c.block_index, c.num_blocks, &lo, &hi);
-        priced += hi - lo;
-    }
-    return priced;
-}
-
 template <bool MARK>  // MARK: the handle prices incrementally, the entering / leaving arc's blocks are flagged
 __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCand* __restrict__ cand, int ncand,
-                                                          int32_t rule, int have_sweep, const int64_t* __restrict__ blk_total) {
+                                                          int32_t rule, int have_sweep) {
     __shared__ PivotShared S;
 #ifdef MCF_STAMPS
     if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = __builtin_amdgcn_s_memtime(); }
@@ -483,11 +478,11 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     // candidate-list rule, minor iteration: no sweep ran; the listed arcs are re-priced here
     // against the current state (resident reduced cost or potentials)
     const bool minor = rule == MCF_RULE_CANDIDATE_LIST && S.ctx.minor_left > 0;
-    // accounting: arcs this pass covers over ALL shards.  Devex: the block's size comes from a host-made table (its
-    // load is in flight during the arg-max; computing it costs 32 emulated 64-bit divisions, ~3 us of lane 0's time)
+    // accounting: arcs this pass covers over ALL shards.  Devex: the block's size comes from the host-made granule
+    // totals (two loads, in flight during the arg-max)
     int64_t priced = minor ? ncand : v.m;
-    if (threadIdx.x == 0 && rule == MCF_RULE_DEVEX_BLOCK && S.ctx.num_blocks > 1)
-        priced = blk_total ? blk_total[S.ctx.block_index] : devex_block_arcs(v, S.ctx);
+    if (threadIdx.x == 0 && rule == MCF_RULE_DEVEX_BLOCK && v.dx && S.ctx.num_blocks > 1)
+        priced = mcf_devex_block_arcs(v.dx, (int32_t)S.ctx.block_index, S.ctx.block_granules);
     for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
         const McfCand cd = i == (int)threadIdx.x ? first : cand[i];
         const int64_t kk = minor ? mcf_minor_key(v, cd.arc) : cd.key;
@@ -520,17 +515,25 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
 //   Devex block / small Dantzig:  one launch runs until optimal / pivot limit.
 //   candidate list:               the launch ends when a full sweep is due (k_price_rc over the whole grid builds
 //                                 the next list); `fresh` says such a sweep ran right before this launch.
-constexpr int kMidTabBlocks = 32;
 
 __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t rule, const McfCand* __restrict__ cand,
                                                               int ncand, int fresh, int max_iters) {
     __shared__ PivotShared S;
-    __shared__ int64_t s_lo[kMidTabBlocks * MCF_NUM_BUCKETS], s_hi[kMidTabBlocks * MCF_NUM_BUCKETS];
+    __shared__ int32_t s_gran[MCF_NUM_BUCKETS][MCF_GRANULES + 1];  // Devex: the granule table (blocks move and resize under the tuner)
+    __shared__ int32_t s_lo[MCF_NUM_BUCKETS], s_hi[MCF_NUM_BUCKETS];  // other rules: the whole buckets
 #ifdef MCF_STAMPS
     if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = __builtin_amdgcn_s_memtime(); }
     __syncthreads();
 #endif
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&S.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
+    const bool devex = rule == MCF_RULE_DEVEX_BLOCK && g.dx;
+    if (devex) {
+        for (int q = threadIdx.x; q < MCF_NUM_BUCKETS * (MCF_GRANULES + 1); q += kPivotThreads)
+            (&s_gran[0][0])[q] = (&g.dx->gran[0][0])[q];
+    } else if (threadIdx.x < MCF_NUM_BUCKETS) {
+        s_lo[threadIdx.x] = (int32_t)g.bucket_off[threadIdx.x];
+        s_hi[threadIdx.x] = (int32_t)g.bucket_off[threadIdx.x + 1];
+    }
     __syncthreads();
     McfView v = g;
     v.ctx = &S.ctx;
@@ -538,22 +541,17 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
     const bool listing = rule == MCF_RULE_CANDIDATE_LIST;
     // the sweep in front of this launch was a no-op if the list was still live (k_price_rc, use_block == 2)
     bool have_fresh = listing && fresh && S.ctx.minor_left <= 0 && S.ctx.status == MCF_RUNNING;
-    const int64_t nb_all = rule == MCF_RULE_DEVEX_BLOCK ? S.ctx.num_blocks : 1;
-    const bool tabulated = nb_all <= kMidTabBlocks;
-    if (!listing) {
-        if (tabulated) {
-            for (int q = threadIdx.x; q < (int)nb_all * MCF_NUM_BUCKETS; q += kPivotThreads)
-                mcf_bucket_slice(g.bucket_off, q % MCF_NUM_BUCKETS, 0, 1, q / MCF_NUM_BUCKETS, nb_all, &s_lo[q], &s_hi[q]);
-        } else if (threadIdx.x < MCF_NUM_BUCKETS) {
-            mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, S.ctx.block_index, nb_all, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
-        }
-    }
-    __syncthreads();
     for (int it = 0; it < max_iters; ++it) {
         // uniform control values are read BEFORE a barrier: lane 0 rewrites them later in this very iteration
         const int32_t status_now = S.ctx.status;
         const int32_t minor_left = S.ctx.minor_left;
-        const int32_t row = tabulated && rule == MCF_RULE_DEVEX_BLOCK ? (int32_t)S.ctx.block_index * MCF_NUM_BUCKETS : 0;
+        int32_t bg0 = 0, bg1 = MCF_GRANULES;  // Devex: granule range of the current block
+        if (devex) {
+            const int32_t bg = S.ctx.block_granules;
+            bg0 = (int32_t)S.ctx.block_index * bg;
+            if (bg0 >= MCF_GRANULES) bg0 = 0;
+            bg1 = bg0 + bg < MCF_GRANULES ? bg0 + bg : MCF_GRANULES;
+        }
         __syncthreads();
         if (status_now != MCF_RUNNING) break;
         MCF_PSTAMP(0);
@@ -575,10 +573,11 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
             // streaming the resident reduced costs
             constexpr int kPer = kPivotThreads / MCF_NUM_BUCKETS;
             const int x = threadIdx.x / kPer, l = threadIdx.x % kPer;
-            const int64_t lo = s_lo[row + x], hi = s_hi[row + x];
+            const int64_t lo = devex ? s_gran[x][bg0] : s_lo[x], hi = devex ? s_gran[x][bg1] : s_hi[x];
             const int64_t* __restrict__ rcache = v.rcache;
             const int8_t* __restrict__ state = v.state;
             int64_t best_i = -1;  // the caller's id is looked up once at the end (and on ties)
+            int32_t best_s = 0;
             constexpr int UM = 4;  // arcs in flight per lane: all loads first (unconditional, clamped), then the arithmetic
             if (hi - lo <= kPer) {  // at most one arc per lane (small Devex blocks): nothing to overlap
                 const int64_t i = lo + l;
@@ -588,6 +587,7 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
                         key = viol;
                         if (rule == MCF_RULE_DEVEX_BLOCK) key = __double_as_longlong(((double)viol * (double)viol) / (double)v.weight[i]);
                         best_i = i;
+                        best_s = state[i];
                     }
                 }
             } else
@@ -615,13 +615,18 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
                         kk = __double_as_longlong(merit);
                     }
                     if (kk < key) continue;
-                    if (kk > key) { key = kk; best_i = i; }
-                    else if (best_i < 0 || v.orig[i] < v.orig[best_i]) best_i = i;
+                    if (kk > key) { key = kk; best_i = i; best_s = sts[u]; }
+                    else if (best_i < 0) { best_i = i; best_s = sts[u]; }
+                    else {
+                        const int32_t a = devex ? mcf_devex_tie_id(v.orig[i], sts[u]) : v.orig[i];
+                        const int32_t b = devex ? mcf_devex_tie_id(v.orig[best_i], best_s) : v.orig[best_i];
+                        if (a < b) { best_i = i; best_s = sts[u]; }
+                    }
                 }
             }
-            if (best_i >= 0) arc = mcf_pack_arc(v.orig[best_i], best_i);
+            if (best_i >= 0) arc = mcf_pack_arc(devex ? mcf_devex_tie_id(v.orig[best_i], best_s) : v.orig[best_i], best_i);
             if (threadIdx.x == 0)
-                for (int x2 = 0; x2 < MCF_NUM_BUCKETS; ++x2) priced += s_hi[row + x2] - s_lo[row + x2];
+                for (int x2 = 0; x2 < MCF_NUM_BUCKETS; ++x2) priced += devex ? s_gran[x2][bg1] - s_gran[x2][bg0] : s_hi[x2] - s_lo[x2];
             block_argmax<kPivotThreads>(key, arc);
         }
         MCF_PSTAMP(1);
@@ -637,8 +642,6 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
         if (threadIdx.x == 0) mcf_stamp_acc[23] += 1;
 #endif
         if (threadIdx.x == 0) S.ctx.apply = 0;
-        if (!listing && !tabulated && threadIdx.x < MCF_NUM_BUCKETS)
-            mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, S.ctx.block_index, nb_all, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
     }
     __syncthreads();
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&S.ctx)[threadIdx.x];
@@ -807,18 +810,15 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     STAMP(0);
 
     McfCtx* c = v.ctx;
-    // per-bucket bounds of every Devex block, tabulated in LDS once: mcf_bucket_slice costs four
-    // emulated 64-bit divisions, and the block advances after every pivot (up to kTabBlocks blocks;
-    // beyond that the bounds of the current block are recomputed by 8 lanes per pivot)
-    constexpr int kTabBlocks = 32;
-    __shared__ int64_t s_lo[kTabBlocks * MCF_NUM_BUCKETS], s_hi[kTabBlocks * MCF_NUM_BUCKETS];
-    const int64_t nb_all = rule == MCF_RULE_DEVEX_BLOCK ? c->num_blocks : 1;
-    const bool tabulated = nb_all <= kTabBlocks;
-    if (tabulated) {
-        for (int q = threadIdx.x; q < (int)nb_all * MCF_NUM_BUCKETS; q += kSmallThreads)
-            mcf_bucket_slice(g.bucket_off, q % MCF_NUM_BUCKETS, 0, 1, q / MCF_NUM_BUCKETS, nb_all, &s_lo[q], &s_hi[q]);
+    // Devex: the host-made granule table in LDS (blocks move and resize under the tuner); other rules: whole buckets
+    __shared__ int32_t s_gran[MCF_NUM_BUCKETS][MCF_GRANULES + 1];
+    const bool devex = rule == MCF_RULE_DEVEX_BLOCK && g.dx;
+    if (devex) {
+        for (int q = threadIdx.x; q < MCF_NUM_BUCKETS * (MCF_GRANULES + 1); q += kSmallThreads)
+            (&s_gran[0][0])[q] = (&g.dx->gran[0][0])[q];
     } else if (threadIdx.x < MCF_NUM_BUCKETS) {
-        mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, c->block_index, nb_all, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
+        s_gran[threadIdx.x][0] = (int32_t)g.bucket_off[threadIdx.x];
+        s_gran[threadIdx.x][MCF_GRANULES] = (int32_t)g.bucket_off[threadIdx.x + 1];
     }
     __syncthreads();
     // candidate-list rule: the list is the best arc of each head bucket (= of each of the 8 pricing
@@ -833,6 +833,13 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         // iteration (mcf_pivot_walk), and a lagging wave must not see the new values
         const int32_t status_now = c->status;
         const bool minor = listing && c->minor_left > 0;
+        int32_t bg0 = 0, bg1 = MCF_GRANULES;  // Devex: granule range of the current block
+        if (devex) {
+            const int32_t bg = c->block_granules;
+            bg0 = (int32_t)c->block_index * bg;
+            if (bg0 >= MCF_GRANULES) bg0 = 0;
+            bg1 = bg0 + bg < MCF_GRANULES ? bg0 + bg : MCF_GRANULES;
+        }
         __syncthreads();
         if (status_now != MCF_RUNNING) break;
         // ---- price: the arc set of k_price for shard 0 of 1
@@ -841,8 +848,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
             // 128 lanes per head bucket, all eight buckets at once
             constexpr int kPer = kSmallThreads / MCF_NUM_BUCKETS;
             const int x = threadIdx.x / kPer, l = threadIdx.x % kPer;
-            const int row = tabulated && rule == MCF_RULE_DEVEX_BLOCK ? (int)c->block_index * MCF_NUM_BUCKETS : 0;
-            const int64_t lo = s_lo[row + x], hi = s_hi[row + x];
+            const int64_t lo = s_gran[x][bg0], hi = s_gran[x][bg1];
             for (int64_t i = lo + l; i < hi; i += kPer) {
                 if (!v.state[i]) continue;
                 const int64_t viol = mcf_violation(v, i);
@@ -852,7 +858,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
                     const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
                     kk = __double_as_longlong(merit);
                 }
-                const int64_t id = mcf_pack_arc(v.orig[i], i);
+                const int64_t id = mcf_pack_arc(devex ? mcf_devex_tie_id(v.orig[i], v.state[i]) : v.orig[i], i);
                 if (mcf_cand_better(kk, id, key, arc)) { key = kk; arc = id; }
             }
         }
@@ -885,9 +891,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         // ---- pivot: one lane walks, everything it touches is in LDS
         if (threadIdx.x == 0) {
             if (c->pivots < c->max_pivots) {
-                const int row = tabulated && rule == MCF_RULE_DEVEX_BLOCK ? (int)c->block_index * MCF_NUM_BUCKETS : 0;
                 int64_t priced = 0;
-                for (int x = 0; x < MCF_NUM_BUCKETS; ++x) priced += s_hi[row + x] - s_lo[row + x];
+                for (int x = 0; x < MCF_NUM_BUCKETS; ++x) priced += s_gran[x][bg1] - s_gran[x][bg0];
                 c->arcs_priced += minor ? MCF_NUM_BUCKETS : priced;
             }
         }
@@ -927,8 +932,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         }
         __syncthreads();
         if (threadIdx.x == 0) c->apply = 0;
-        if (!tabulated && threadIdx.x < MCF_NUM_BUCKETS)
-            mcf_bucket_slice(g.bucket_off, threadIdx.x, 0, 1, c->block_index, nb_all, &s_lo[threadIdx.x], &s_hi[threadIdx.x]);
         __syncthreads();
         STAMP(5);
     }
@@ -986,8 +989,7 @@ struct mcf_handle {
     int32_t *d_pos0 = nullptr, *d_pos1 = nullptr, *d_psz0 = nullptr, *d_psz1 = nullptr;
     McfDirty* d_dirty = nullptr;
     int64_t* d_swept = nullptr;  // arcs swept per pricing workgroup (summed by mcf_get_result)
-    int32_t* d_blk_tab = nullptr;  // Devex: (lo, hi) of this rank's share of block k of bucket x, [num_blocks][8][2]
-    int64_t* d_blk_total = nullptr;  // Devex: arcs of block k over all shards (accounting)
+    McfDevex* d_dx = nullptr;        // Devex: granule table + touched-weight list
     int32_t* d_full_tab = nullptr;   // sharded full sweeps: (lo, hi) of this rank's share of bucket x, [8][2]
     bool rcached = false;     // large instance: resident reduced costs + k_rcupd
     int rcupd_blocks = 1;
@@ -1067,13 +1069,12 @@ int upload_image(mcf_handle* h) {
     McfCtx c;
     std::memset(&c, 0, sizeof c);
     c.unbounded_arc = -1;
-    int64_t bs = h->opt.block_size;
     const int64_t m = im.m;
-    if (bs <= 0) bs = m < 1000 ? m / 4 : (m < 10000 ? m / 8 : m / 16);  // simplex_adaptive.py:89-96
-    if (bs < 1) bs = 1;
-    c.block_size = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? bs : (m > 0 ? m : 1);
-    c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
-    if (c.num_blocks < 1) c.num_blocks = 1;
+    mcf_init_block_state(&c, h->opt.rule, m, h->opt.block_size);
+    if (h->opt.rule == MCF_RULE_DEVEX_BLOCK) {
+        if (h->opt.devex_tuner > 0) c.auto_tune = 1; else if (h->opt.devex_tuner < 0) c.auto_tune = 0;
+        if (h->opt.devex_stay > 0) c.devex_cyclic = 0;
+    }
     c.minor_cap = mcf_minor_cap(h->price_blocks);
     c.climb_budget = h->climb_budget;
     *h->h_ctx = c;
@@ -1087,26 +1088,16 @@ int upload_image(mcf_handle* h) {
         if (dalloc(&h->d_full_tab, MCF_NUM_BUCKETS * 2) != hipSuccess) { h->err = "hipMalloc slice table"; return MCF_E_ALLOC; }
         HIP_TRY(h, hipMemcpy(h->d_full_tab, tab, sizeof tab, hipMemcpyHostToDevice));
     }
-    if (h->opt.rule == MCF_RULE_DEVEX_BLOCK && c.num_blocks <= 4096 && !h->d_blk_tab) {  // block bounds, once
-        std::vector<int32_t> tab((size_t)c.num_blocks * MCF_NUM_BUCKETS * 2);
-        for (int64_t k = 0; k < c.num_blocks; ++k)
-            for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
-                int64_t lo, hi;
-                mcf_bucket_slice(im.bucket_off, x, h->shard, h->shards, k, c.num_blocks, &lo, &hi);
-                tab[(k * MCF_NUM_BUCKETS + x) * 2] = (int32_t)lo;
-                tab[(k * MCF_NUM_BUCKETS + x) * 2 + 1] = (int32_t)hi;
-            }
-        if (dalloc(&h->d_blk_tab, tab.size()) != hipSuccess) { h->err = "hipMalloc block table"; return MCF_E_ALLOC; }
-        HIP_TRY(h, hipMemcpy(h->d_blk_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
-        std::vector<int64_t> total(c.num_blocks, 0);
-        for (int64_t k = 0; k < c.num_blocks; ++k)
-            for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
-                int64_t lo, hi;
-                mcf_bucket_slice(im.bucket_off, x, 0, 1, k, c.num_blocks, &lo, &hi);
-                total[k] += hi - lo;
-            }
-        if (dalloc(&h->d_blk_total, total.size()) != hipSuccess) { h->err = "hipMalloc block table"; return MCF_E_ALLOC; }
-        HIP_TRY(h, hipMemcpy(h->d_blk_total, total.data(), total.size() * 8, hipMemcpyHostToDevice));
+    if (h->opt.rule == MCF_RULE_DEVEX_BLOCK && !h->d_dx) {  // granule table, once
+        McfDevex* dx = new (std::nothrow) McfDevex();
+        if (!dx) { h->err = "host allocation"; return MCF_E_ALLOC; }
+        std::memset(dx, 0, sizeof *dx);
+        mcf_devex_fill_granules(dx, im.bucket_off);
+        hipError_t de = dalloc(&h->d_dx, 1);
+        if (de == hipSuccess) de = hipMemcpy(h->d_dx, dx, sizeof *dx, hipMemcpyHostToDevice);
+        delete dx;
+        if (de != hipSuccess) { h->err = "hipMalloc / copy granule table"; return MCF_E_ALLOC; }
+        h->view.dx = h->d_dx;
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_ctx, h->h_ctx, sizeof(McfCtx), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1117,7 +1108,7 @@ int upload_image(mcf_handle* h) {
         mcf_bucket_slice(im.bucket_off, x, h->shard, h->shards, 0, 1, &lo, &hi);
         h->shard_arcs += hi - lo;
     }
-    h->priced_per_pass = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? (h->shard_arcs + c.num_blocks - 1) / c.num_blocks : h->shard_arcs;
+    h->priced_per_pass = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? h->shard_arcs * c.block_granules / MCF_GRANULES : h->shard_arcs;
     std::memset(&h->stats, 0, sizeof h->stats);
     h->stats.unbounded_arc = -1;
     h->stats.price_bytes = (h->opt.rule == MCF_RULE_DEVEX_BLOCK ? 17 : 13) * h->priced_per_pass + 8 * (int64_t)im.n_nodes;
@@ -1135,7 +1126,7 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
     if (rule == MCF_RULE_CANDIDATE_LIST && use_block) use_block = 2;
     if (h->rcached) {
         if (rule == MCF_RULE_DEVEX_BLOCK)
-            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, use_block == 1 ? h->d_blk_tab : nullptr);
+            hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)nullptr);
         else
             if (v.dirty) hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, true>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)h->d_full_tab);
             else hipLaunchKernelGGL((k_price_rc<MCF_RULE_DANTZIG, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)h->d_full_tab);
@@ -1148,8 +1139,8 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
 }
 
 void launch_k_pivot(mcf_handle* h, hipStream_t s, const McfCand* cand, int ncand, int32_t rule, int have_sweep) {
-    if (h->view.dirty) hipLaunchKernelGGL(k_pivot<true>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep, (const int64_t*)h->d_blk_total);
-    else hipLaunchKernelGGL(k_pivot<false>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep, (const int64_t*)h->d_blk_total);
+    if (h->view.dirty) hipLaunchKernelGGL(k_pivot<true>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep);
+    else hipLaunchKernelGGL(k_pivot<false>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep);
 }
 
 void launch_apply(mcf_handle* h, hipStream_t s) {
@@ -1239,7 +1230,7 @@ void free_all(mcf_handle* h) {
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
-    (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_blk_tab); (void)hipFree(h->d_blk_total); (void)hipFree(h->d_full_tab);
+    (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_dx); (void)hipFree(h->d_full_tab);
     (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
     if (h->h_one) (void)hipHostFree(h->h_one);
@@ -1352,6 +1343,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     v.tail = h->d_tail; v.head = h->d_head; v.cost = h->d_cost; v.orig = h->d_orig; v.state = h->d_state;
     for (int x = 0; x <= MCF_NUM_BUCKETS; ++x) v.bucket_off[x] = im.bucket_off[x];
     v.weight = opt.rule == MCF_RULE_DEVEX_BLOCK ? h->d_weight : nullptr;
+    v.dx = nullptr;  // (allocated and filled by upload_image for the Devex rule)
     v.arcw = h->d_arcw; v.pi = h->d_pi; v.node = h->d_node;
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
     v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
@@ -1417,9 +1409,10 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     {
         int64_t per_pivot_arcs = 0;
         if (opt.rule == MCF_RULE_DEVEX_BLOCK) {
-            int64_t bs = opt.block_size;
-            if (bs <= 0) bs = im.m < 1000 ? im.m / 4 : (im.m < 10000 ? im.m / 8 : im.m / 16);
-            per_pivot_arcs = bs < 1 ? 1 : bs;
+            McfCtx probe;  // the largest block the tuner may grow to (mcf_core.h: never beyond MCF_TUNER_MAX_ARCS or the initial size)
+            std::memset(&probe, 0, sizeof probe);
+            mcf_init_block_state(&probe, opt.rule, im.m, opt.block_size);
+            per_pivot_arcs = im.m * probe.max_granules / MCF_GRANULES;
         } else if (opt.rule == MCF_RULE_DANTZIG_FULL) {
             per_pivot_arcs = im.m;
         }
@@ -1484,6 +1477,12 @@ int mcf_set_max_pivots(mcf_handle* h, int64_t max_total_pivots) {
 
 int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user, int64_t cb_interval) {
     if (!h) return MCF_E_BAD_ARG;
+    if (h->shards != 1) {
+        // a sharded handle prices 1/shard_count of the arcs: on its own it would declare "optimal" as soon as ITS share
+        // holds no eligible arc.  It is only valid inside the price -> all-gather -> pivot protocol below.
+        h->err = "mcf_solve: handle was created with shard_count > 1; drive it with mcf_enqueue_price / mcf_enqueue_pivot";
+        return MCF_E_STATE;
+    }
     HIP_TRY(h, hipSetDevice(h->device));
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t m = h->im.m, n = h->im.n;
@@ -1657,7 +1656,7 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
     HIP_TRY(h, hipMemcpyAsync(h->h_one, h->d_one, sizeof(McfCand), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const bool found = h->h_one->key > 0 && h->h_one->arc >= 0;
-    *arc = found ? (h->h_one->arc >> 32) : -1;  // caller's arc index
+    *arc = found ? ((h->h_one->arc >> 32) & (MCF_DIR_FLAG - 1)) : -1;  // caller's arc index (Devex ids carry the direction in bit 30)
     if (key) *key = found ? h->h_one->key : 0;
     if (dir) {
         *dir = 0;
@@ -1672,6 +1671,7 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
 
 int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev) {
     if (!h || !cand_out_dev) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int32_t rule = h->opt.rule;
     launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG);
@@ -1683,6 +1683,7 @@ int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev) {
 
 int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int32_t ncand) {
     if (!h || !cands_dev || ncand < 1) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     launch_k_pivot(h, s, reinterpret_cast<const McfCand*>(cands_dev), ncand, h->opt.rule, 1);
     launch_apply(h, s);
@@ -1692,6 +1693,7 @@ int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int
 
 int mcf_poll(mcf_handle* h, void* stream, int32_t* status_or_running, int64_t* pivots) {
     if (!h) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
     const int rc = read_ctx(h, static_cast<hipStream_t>(stream));
     if (rc) return rc;
     if (h->h_ctx->status == MCF_INTERNAL_ERROR) { h->err = "internal error: preorder permutation did not close"; return MCF_E_INTERNAL; }
@@ -1810,6 +1812,17 @@ int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident) {
         HIP_TRY(h, hipMemcpy(pi.data(), h->d_pi, pi.size() * 8, hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < im.m; ++i) rc_out[im.orig[i]] = im.cost64[i] + pi[im.tail[i]] - pi[im.head[i]];
     }
+    return MCF_OK;
+}
+
+int mcf_get_weights(mcf_handle* h, float* weight_out) {
+    if (!h || !weight_out) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const McfHostImage& im = h->im;
+    std::vector<float> w(im.m_pad);
+    HIP_TRY(h, hipMemcpy(w.data(), h->d_weight, w.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < im.m; ++i) weight_out[im.orig[i]] = w[i];
     return MCF_OK;
 }
 

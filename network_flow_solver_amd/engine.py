@@ -19,6 +19,7 @@ from .exceptions import NetworkSolverError
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MCF_HIP_LIB", _PKG / "libmcf_hip.so"))  # override: A/B builds of the same ABI
 
+ABI_VERSION = 2
 RULE_DANTZIG = 0
 RULE_DEVEX_BLOCK = 1
 RULE_CANDIDATE_LIST = 2
@@ -29,7 +30,7 @@ CAP_INF = -1
 ABI_SYMBOLS = (
     "mcf_default_options", "mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis",
     "mcf_enqueue_price", "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing",
-    "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_dimacs_scan", "mcf_dimacs_load", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
+    "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_get_weights", "mcf_dimacs_scan", "mcf_dimacs_load", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
 )
 
 
@@ -52,6 +53,7 @@ class McfOptions(ctypes.Structure):
         ("block_size", ctypes.c_int64), ("shard_rank", ctypes.c_int64), ("shard_count", ctypes.c_int64),
         ("price_blocks", ctypes.c_int32), ("no_fused", ctypes.c_int32), ("no_rcache", ctypes.c_int32),
         ("cycle_scan", ctypes.c_int32), ("mid_loop", ctypes.c_int32), ("full_sweeps", ctypes.c_int32),
+        ("devex_tuner", ctypes.c_int32), ("devex_stay", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4),
     ]
 
 
@@ -107,6 +109,7 @@ def load_library():
     lib.mcf_time_copy.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
     lib.mcf_get_tree.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i8p, i64p, i32p, i32p]
     lib.mcf_get_reduced_costs.argtypes = [vp, i64p, i32p]
+    lib.mcf_get_weights.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.mcf_dimacs_scan.argtypes = [ctypes.c_char_p, i64p, i64p, ctypes.c_char_p, ctypes.c_int32]
     lib.mcf_dimacs_load.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, i64p,
                                     ctypes.c_char_p, ctypes.c_int32]
@@ -116,9 +119,9 @@ def load_library():
     lib.mcf_destroy.restype = None
     for name in ("mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis", "mcf_enqueue_price",
                  "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing", "mcf_time_copy",
-                 "mcf_get_tree", "mcf_get_reduced_costs", "mcf_dimacs_scan", "mcf_dimacs_load"):
+                 "mcf_get_tree", "mcf_get_reduced_costs", "mcf_get_weights", "mcf_dimacs_scan", "mcf_dimacs_load"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.mcf_abi_version() != 1:
+    if lib.mcf_abi_version() != ABI_VERSION:
         raise EngineUnavailableError("libmcf_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -148,7 +151,8 @@ class McfEngine:
     def __init__(self, n: int, tail, head, cost, cap, supply, rule: int = RULE_DANTZIG, block_size: int = 0,
                  batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
                  shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
-                 resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0, full_sweeps: int = 0):
+                 resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0, full_sweeps: int = 0,
+                 devex_tuner: int = 0, devex_stay: bool = False):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -180,6 +184,8 @@ class McfEngine:
         opt.cycle_scan = int(cycle_scan)
         opt.mid_loop = int(mid_loop)
         opt.full_sweeps = int(full_sweeps)   # 0 auto, 1 never incremental, -1 always incremental
+        opt.devex_tuner = int(devex_tuner)   # 0 auto (on unless block_size is given), 1 on, -1 off
+        opt.devex_stay = 1 if devex_stay else 0
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule
@@ -302,6 +308,12 @@ class McfEngine:
         res = ctypes.c_int32(0)
         self._check(self._lib.mcf_get_reduced_costs(self._h, _p(rc, ctypes.c_int64), ctypes.byref(res)))
         return rc[: self.m], bool(res.value)
+
+    def weights(self) -> np.ndarray:
+        """Devex reference weights per arc (caller's order)."""
+        w = np.ones(max(self.m, 1), dtype=np.float32)
+        self._check(self._lib.mcf_get_weights(self._h, _p(w, ctypes.c_float)))
+        return w[: self.m]
 
     # -- measurement
     def time_pricing(self, reps: int = 20, rule: int | None = None) -> float:

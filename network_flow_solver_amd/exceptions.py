@@ -47,7 +47,7 @@ class IterationLimitError(NetworkSolverError):
     """Optional strict-mode error (exceptions.py:124-154)."""
 
     def __init__(self, message: str, iterations: int = 0, objective: float | None = None,
-                 status: str = "iteration_limit"):
+                 status: str = "unknown"):
         super().__init__(message)
         self.iterations = iterations
         self.objective = objective

@@ -66,13 +66,15 @@ def _decimal_scale(values: np.ndarray, what: str) -> int:
         f"represent them exactly")
 
 
-def flatten_problem(problem: NetworkProblem) -> FlatProblem:
-    """NetworkProblem -> integer SoA, in the reference's internal order."""
+def flatten_problem(problem: NetworkProblem, tolerance: float | None = None) -> FlatProblem:
+    """NetworkProblem -> integer SoA, in the reference's internal order.  ``tolerance`` is the solver's
+    (``SolverOptions.tolerance``, simplex.py:154): the balance and bound checks below are the solver's own
+    (:381-412), not the problem's build-time ones."""
     node_ids = sorted(problem.nodes.keys())                       # simplex.py:149
     index = {nid: i for i, nid in enumerate(node_ids)}
     arcs = sorted(problem.undirected_expansion(), key=lambda a: (a.tail, a.head))  # simplex.py:394-395
     m = len(arcs)
-    tol = problem.tolerance
+    tol = problem.tolerance if tolerance is None else tolerance
     supply = np.array([problem.nodes[nid].supply for nid in node_ids], dtype=np.float64)
     if abs(float(supply.sum())) > tol:                            # simplex.py:381-390
         raise InvalidProblemError(
@@ -103,7 +105,12 @@ def flatten_problem(problem: NetworkProblem) -> FlatProblem:
     supply_i = np.round(supply * flow_scale).astype(np.int64)
     residual = int(supply_i.sum())
     if residual != 0:
-        # the reference tolerates |sum| <= tolerance; put the sub-tolerance remainder on the largest node
+        # the reference tolerates |sum| <= tolerance (checked above); the integer engine needs an exact balance:
+        # the sub-tolerance remainder goes onto the largest node -- never more than the tolerance allows
+        if abs(residual) > tol * flow_scale + 1:
+            raise InvalidProblemError(
+                f"Supplies do not balance after lower-bound adjustment: total supply {residual / flow_scale:.6f} "
+                f"exceeds tolerance {tol}.")
         supply_i[int(np.argmax(np.abs(supply_i)))] -= residual
     cost_i = np.round(cost * cost_scale).astype(np.int64)
     if m and (np.abs(cost_i).max() >= 2 ** 31 or (cap_i.max() >= 2 ** 60)):
@@ -132,7 +139,7 @@ class NetworkSimplex:
         self.logger = logging.getLogger(__name__)
         self.problem = problem
         self.tolerance = self.options.tolerance
-        self.flat = flatten_problem(problem)
+        self.flat = flatten_problem(problem, self.tolerance)
         self.node_ids = [self.ROOT_NODE] + self.flat.node_ids
         self.actual_arc_count = len(self.flat.keys)
         self.degenerate_pivots = 0

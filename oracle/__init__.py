@@ -62,6 +62,11 @@ def _load():
             ctypes.c_int64, i32p, i32p, f64p, f64p, f64p, f64p, u8p, ctypes.c_double, ctypes.c_int,
             ctypes.POINTER(ctypes.c_int),
         ]
+        lib.ref_price_block.restype = ctypes.c_int64
+        lib.ref_price_block.argtypes = [
+            ctypes.c_int64, i32p, i32p, f64p, f64p, f64p, f64p, u8p, f64p, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_double, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), f64p,
+        ]
         _lib = lib
     return _lib
 
@@ -254,6 +259,28 @@ def price_dantzig(tail, head, cost, potential, fwd_res, bwd_res, in_tree, tolera
         _ptr(np.ascontiguousarray(in_tree, np.uint8), ctypes.c_uint8),
         float(tolerance), 1 if allow_zero else 0, ctypes.byref(d))
     return None if arc < 0 else (int(arc), int(d.value))
+
+
+def price_block(tail, head, cost, potential, fwd_res, bwd_res, in_tree, weights, start, end, tolerance=1e-6,
+                allow_zero=False, excluded=-1):
+    """One vectorised block selection (NetworkSimplex._select_entering_arc_vectorized, simplex.py:528-617) over
+    arcs [start, end).  Returns (arc, dir, merit) or None."""
+    lib = _load()
+    m = int(len(tail))
+    d = ctypes.c_int(0)
+    merit = ctypes.c_double(0.0)
+    arc = lib.ref_price_block(
+        m, _ptr(np.ascontiguousarray(tail, np.int32), ctypes.c_int32),
+        _ptr(np.ascontiguousarray(head, np.int32), ctypes.c_int32),
+        _ptr(np.ascontiguousarray(cost, np.float64), ctypes.c_double),
+        _ptr(np.ascontiguousarray(potential, np.float64), ctypes.c_double),
+        _ptr(np.ascontiguousarray(fwd_res, np.float64), ctypes.c_double),
+        _ptr(np.ascontiguousarray(bwd_res, np.float64), ctypes.c_double),
+        _ptr(np.ascontiguousarray(in_tree, np.uint8), ctypes.c_uint8),
+        _ptr(np.ascontiguousarray(weights, np.float64), ctypes.c_double),
+        int(start), int(end), float(tolerance), 1 if allow_zero else 0, int(excluded), ctypes.byref(d),
+        ctypes.byref(merit))
+    return None if arc < 0 else (int(arc), int(d.value), float(merit.value))
 
 
 # ---------------------------------------------------------------------------

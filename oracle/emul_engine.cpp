@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../network_flow_solver_amd/csrc/mcf_host.h"
@@ -28,6 +29,7 @@ struct Emul {
     int rule = 0;
     int price_blocks = 8;
     std::vector<McfCand> cand;  // candidate-list rule: one entry per (virtual) pricing workgroup
+    McfDevex dx;                // Devex: granule table + touched-weight list
 };
 
 void bind(Emul& e) {
@@ -53,6 +55,8 @@ void bind(Emul& e) {
     for (int x = 0; x <= MCF_NUM_BUCKETS; ++x) v.bucket_off[x] = im.bucket_off[x];
     v.state = im.state.data();
     v.weight = e.rule == MCF_RULE_DEVEX_BLOCK ? im.weight.data() : nullptr;
+    v.dx = e.rule == MCF_RULE_DEVEX_BLOCK ? &e.dx : nullptr;
+    mcf_devex_fill_granules(&e.dx, im.bucket_off);
     v.arcw = im.arcw.data();
     v.pi = im.pi.data();
     v.node = im.node.data();
@@ -84,15 +88,15 @@ void bind(Emul& e) {
 // workgroup, using the kernel's arc -> workgroup map.  Returns the number of arcs looked at.
 int64_t price(Emul& e, int64_t r, int64_t G, int64_t* key, int64_t* arc) {
     const McfView& v = e.view;
-    const int64_t nb = e.rule == MCF_RULE_DEVEX_BLOCK ? v.ctx->num_blocks : 1;
-    const int64_t k = e.rule == MCF_RULE_DEVEX_BLOCK ? v.ctx->block_index : 0;
+    const bool devex = e.rule == MCF_RULE_DEVEX_BLOCK;
     const bool listing = e.rule == MCF_RULE_CANDIDATE_LIST;
     const int64_t nlb = e.price_blocks / MCF_NUM_BUCKETS;
     if (listing) e.cand.assign(e.price_blocks, McfCand{0, -1});
     int64_t bk = 0, ba = -1, priced = 0;
     for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
         int64_t lo, hi;
-        mcf_bucket_slice(v.bucket_off, x, r, G, k, nb, &lo, &hi);
+        if (devex) mcf_devex_slice(v.dx, x, r, G, (int32_t)v.ctx->block_index, v.ctx->block_granules, &lo, &hi);
+        else mcf_bucket_slice(v.bucket_off, x, r, G, 0, 1, &lo, &hi);
         priced += hi - lo;
         const int64_t g_lo = lo >> 2;
         for (int64_t i = lo; i < hi; ++i) {
@@ -104,7 +108,7 @@ int64_t price(Emul& e, int64_t r, int64_t G, int64_t* key, int64_t* arc) {
                 const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
                 std::memcpy(&kk, &merit, 8);
             }
-            const int64_t id = mcf_pack_arc(v.orig[i], i);
+            const int64_t id = mcf_pack_arc(devex ? mcf_devex_tie_id(v.orig[i], v.state[i]) : v.orig[i], i);
             if (mcf_cand_better(kk, id, bk, ba)) { bk = kk; ba = id; }
             if (listing) {
                 McfCand& c = e.cand[(((i >> 2) - g_lo) >> 8) % nlb * MCF_NUM_BUCKETS + x];
@@ -132,11 +136,9 @@ int64_t price_minor(Emul& e, const McfCand* cands, int64_t ncand, int64_t* key, 
 void init_blocks(Emul& e, int64_t block_size) {
     McfCtx& c = e.ctx;
     const int64_t m = e.im.m;
-    if (block_size <= 0) block_size = m < 1000 ? m / 4 : (m < 10000 ? m / 8 : m / 16);  // simplex_adaptive.py:89-96
-    if (block_size < 1) block_size = 1;
-    c.block_size = e.rule == MCF_RULE_DEVEX_BLOCK ? block_size : (m > 0 ? m : 1);
-    c.num_blocks = (int32_t)((m + c.block_size - 1) / c.block_size);
-    if (c.num_blocks < 1) c.num_blocks = 1;
+    mcf_init_block_state(&c, e.rule, m, block_size);
+    if (std::getenv("MCF_DEVEX_CYCLIC")) c.devex_cyclic = std::atoi(std::getenv("MCF_DEVEX_CYCLIC"));
+    if (std::getenv("MCF_DEVEX_NOTUNE")) c.auto_tune = 0;
     e.price_blocks = mcf_price_blocks(m, 1, 0);
     c.minor_cap = mcf_minor_cap(e.price_blocks);
 }
@@ -177,7 +179,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         const int64_t priced = minor ? price_minor(e, e.cand.data(), (int64_t)e.cand.size(), &key, &arc)
                                      : price(e, 0, 1, &key, &arc);
         if (c.pivots < c.max_pivots) c.arcs_priced += priced;
-        if (trace_arcs && ntrace < trace_cap) trace_arcs[ntrace++] = arc < 0 ? -1 : (arc >> 32);
+        if (trace_arcs && ntrace < trace_cap) trace_arcs[ntrace++] = arc < 0 ? -1 : ((arc >> 32) & (MCF_DIR_FLAG - 1));
         mcf_pivot_seq(e.view, key, arc, rule);
         if (c.apply) {
             // the two ranges the apply kernel covers: this pivot's and the stale one

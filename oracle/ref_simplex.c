@@ -720,3 +720,25 @@ int64_t ref_price_dantzig(int64_t m, const int32_t *tail, const int32_t *head, c
     *dir_out = dir;
     return found ? arc : -1;
 }
+
+/* One vectorised block-selection pass over caller-provided state (simplex.py:528-617 via
+ * select_block_vectorized above): eligibility, merit rc^2 / w, first maximum per direction,
+ * forward wins only when strictly greater.  Used by the kernel-level Devex parity test.
+ * Returns the arc index or -1; *dir_out = +1/-1; *merit_out = the winning merit. */
+int64_t ref_price_block(int64_t m, const int32_t *tail, const int32_t *head, const double *cost,
+                        const double *potential, const double *fwd_res, const double *bwd_res,
+                        const uint8_t *in_tree, const double *weights, int64_t start, int64_t end,
+                        double tol, int allow_zero, int64_t excluded, int *dir_out, double *merit_out) {
+    Ref S; memset(&S, 0, sizeof S);
+    S.m_real = m; S.m_tot = m; S.tol = tol;
+    S.tail = (int32_t *)tail; S.head = (int32_t *)head; S.vec_cost = (double *)cost;
+    S.potential = (double *)potential; S.fwd_res = (double *)fwd_res; S.bwd_res = (double *)bwd_res;
+    S.in_tree = (uint8_t *)in_tree; S.weights = (double *)weights;
+    uint8_t *art = xcalloc((size_t)m, 1);
+    S.artificial = art;
+    int64_t arc = -1; int dir = 0; double merit = 0.0;
+    int found = select_block_vectorized(&S, start, end, allow_zero, excluded, &arc, &dir, &merit);
+    free(art);
+    *dir_out = dir; *merit_out = merit;
+    return found ? arc : -1;
+}

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(engine.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert engine.load_library().mcf_abi_version() == 1
+    assert engine.load_library().mcf_abi_version() == engine.ABI_VERSION == 2
 
 
 def test_struct_layouts_match_the_header():
@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header():
         for line in body.splitlines():
             line = line.split("/*")[0].strip()
             if line.endswith(";") and "(" not in line:
-                out.append(line[:-1].split()[-1])
+                out.append(line[:-1].split()[-1].split("[")[0])
         return out
 
     assert fields("mcf_options") == [f for f, _ in engine.McfOptions._fields_]

@@ -183,3 +183,42 @@ def test_incremental_pricing_block_map_matches_the_sweep(price_blocks, shard, sh
     for inst in (generators.netgen_style(300, 2400, seed=5), generators.netgen_style(5000, 70001, seed=6),
                  generators.goto_style(40, 40, seed=7)):
         assert oracle.emul_check_block_map(inst, price_blocks, shard, shards) == 0
+
+
+def test_devex_pivot_counts_stay_close_to_the_reference():
+    """The engine's Devex rule (cyclic block search + the reference's weight reset every 64 basis swaps + its
+    block-size tuner) against the reference's own Devex pivot counts (goldens made by running the reference):
+    at most 1.2x on every instance.  Without the reset the same rule took 2.4x (netgen_8_12a, round 1)."""
+    seen = 0
+    for entry, inst in load_synthetic():
+        exp = entry["expected"].get("devex")
+        if not exp or "iterations" not in exp:
+            continue
+        res = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=1)
+        assert res["status"] == "optimal" and res["objective"] == int(round(exp["objective"]))
+        assert res["pivots"] <= 1.2 * exp["iterations"], (entry["name"], res["pivots"], exp["iterations"])
+        seen += 1
+    assert seen >= 5
+
+
+def test_restated_block_selection_tie_rules():
+    """oracle.price_block (the restated _select_entering_arc_vectorized, simplex.py:528-617) on a hand-made state:
+    first maximum per direction, forward only when strictly greater, weights divide the squared reduced cost."""
+    tail = np.array([0, 0, 1, 1, 2, 2], np.int32)
+    head = np.array([1, 2, 2, 3, 3, 0], np.int32)
+    pot = np.zeros(4)
+    inf = np.inf
+    #        forward rc=-4   fwd rc=-4    backward rc=+4  bwd rc=+6/w=4   basic       fwd rc=-2
+    cost = np.array([-4.0, -4.0, 4.0, 6.0, -9.0, -2.0])
+    fwd = np.array([5.0, 5.0, 0.0, 0.0, 5.0, 5.0])
+    bwd = np.array([0.0, 0.0, 3.0, 3.0, 0.0, 0.0])
+    in_tree = np.array([0, 0, 0, 0, 1, 0], np.uint8)
+    w = np.array([1.0, 1.0, 1.0, 4.0, 1.0, 1.0])
+    # merits: 16, 16, 16 (backward), 9 (backward), -, 4: forward/backward tie -> backward arc 2
+    assert oracle.price_block(tail, head, cost, pot, fwd, bwd, in_tree, w, 0, 6) == (2, -1, 16.0)
+    # without the backward candidates: lowest index among the equal forward merits
+    assert oracle.price_block(tail, head, cost, pot, fwd, bwd, in_tree, w, 0, 2) == (0, 1, 16.0)
+    assert oracle.price_block(tail, head, cost, pot, fwd, bwd, in_tree, w, 1, 2) == (1, 1, 16.0)
+    assert oracle.price_block(tail, head, cost, pot, fwd, bwd, in_tree, w, 3, 6) == (3, -1, 9.0)
+    assert oracle.price_block(tail, head, cost, pot, fwd, bwd, in_tree, w, 4, 5) is None
+    del inf
