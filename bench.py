@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- pivots/sec + arcs-priced/sec of the MI355X network-simplex engine.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--rule R] [--scaling weak|strong]
 
 A *step* is one pivot: one pass of the hot path (pricing sweep -> ratio test / flow update
 -> tree + potential update) over the device-resident instance.  W untimed pivots, then
@@ -10,15 +10,24 @@ ONE JSON line.  Inputs are resident in HBM before the timed region starts.
 
 Workload at N=1 (default): BASELINE.json configs[1] -- "netgen_8_08a, 1xMI355X, full-scan
 Dantzig pricing kernel" -- as a seeded synthetic stand-in (the LEMON file is not obtainable
-offline).  That instance is 27 KB per sweep, i.e. launch-latency-bound by construction, so
-the same line also carries ``hbm_point``: the same measurement on BASELINE.json configs[4]'s
-shape (1M nodes / 16M arcs), the one configuration whose pricing sweep is HBM-bound and for
-which BASELINE.json asks for the roofline fraction.
+offline).  That instance is 27 KB per sweep: it runs as ONE persistent LDS-resident workgroup
+(k_solve_small) and is latency-bound by construction, which is what its `roofline` object says.
+The same line therefore also carries
+  * ``hbm_point``: configs[4]'s shape (1 M nodes / 16 M arcs), where the pricing sweep (k_price_rc) is the dominant,
+    bandwidth-bound kernel -- its 151 MB working set still fits the 256 MiB Infinity Cache;
+  * ``hbm_point_beyond_infinity_cache``: 4 M nodes / 64 M arcs (604 MB per sweep), where the same kernel really
+    streams from HBM;
+  * ``config_points``: the other single-GPU-runnable BASELINE.json configs with the engine's defaults.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Every rank holds the
-replicated instance, prices its own contiguous arc shard, and one 16-byte all-gather per
-pivot picks the entering arc.  Weak scaling: arcs per GPU are fixed,
-``value`` is the whole-job arcs-priced/sec.
+``roofline`` always describes the kernel the timed region ran.  ``achieved`` = the kernel's own compulsory bytes per
+launch (9 B per arc for the resident-reduced-cost sweep, 13 B with Devex weights) / its launch
+duration measured with HIP events on the engine's stream; ``traffic`` = HBM-side bytes per launch from the committed
+rocprofv3 PMC passes (profiles/pmc_traffic.json).  SURVEY.md section 8d's per-arc figure for the gather formulation
+(13 B/arc + 8 B/node) is kept as ``survey_8d`` for comparison; it is not a physical rate of this kernel.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); ``python bench.py --gpus N`` without a
+launcher spawns the N ranks itself.  Every rank holds the replicated instance, prices its own arc shard, and one small
+all-gather per sweep picks the entering arc(s).
 """
 
 from __future__ import annotations
@@ -26,6 +35,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,10 +46,10 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 
 WORKLOADS = {
-    # name: (family builder args) -- per-GPU shape; at N GPUs the instance has N x the arcs and nodes
+    # name: (family builder args) -- per-GPU shape under weak scaling
     "netgen_8_08a": ("netgen", 256, 2048),
     "gridgen_8_14a": ("gridgen", 128, 128),      # BASELINE.json configs[2]: 16 385 nodes / 131 080 arcs
     "goto_8_16a": ("goto", 256, 256),            # BASELINE.json configs[3]: 65 536 nodes / 524 288 arcs
@@ -48,22 +58,36 @@ WORKLOADS = {
     "netgen_8_18a": ("netgen", 262144, 2097152),
     "netgen_8_20a": ("netgen", 1 << 20, 8 << 20),
     "netgen_1m_16m": ("netgen", 1 << 20, 16 << 20),
+    "netgen_4m_64m": ("netgen", 4 << 20, 64 << 20),   # working set beyond the 256 MiB Infinity Cache
 }
+RULE_NAMES = {0: "full-scan Dantzig", 1: "block-search Devex", 2: "candidate list"}
+MODE_NAMES = {0: "gather sweep", 1: "resident reduced costs", 2: "fused LDS loop", 3: "persistent single-workgroup loop"}
+
+_instances: dict = {}
 
 
 def make_instance(workload: str, scale: int = 1):
     from network_flow_solver_amd import generators
 
-    fam, n, m = WORKLOADS[workload]
-    if fam == "gridgen":
-        return generators.gridgen_style(n * scale, m, seed=1, name=f"{workload}(synthetic,x{scale})")
-    if fam == "goto":
-        return generators.goto_style(n * scale, m, seed=1, name=f"{workload}(synthetic,x{scale})")
-    return generators.netgen_style(n * scale, m * scale, seed=1, name=f"{workload}(synthetic,x{scale})")
+    key = (workload, scale)
+    if key not in _instances:
+        fam, n, m = WORKLOADS[workload]
+        name = f"{workload}(synthetic,x{scale})"
+        if fam == "gridgen":
+            inst = generators.gridgen_style(n * scale, m, seed=1, name=name)
+        elif fam == "goto":
+            inst = generators.goto_style(n * scale, m, seed=1, name=name)
+        else:
+            inst = generators.netgen_style(n * scale, m * scale, seed=1, name=name)
+        if len(_instances) >= 2:                 # keep the process small: at most two instances stay cached
+            _instances.pop(next(iter(_instances)))
+        _instances[key] = inst
+    return _instances[key]
 
 
-def run_pivots(eng, count: int):
-    """Exactly `count` more pivots; restarts from the start basis when the optimum is reached."""
+def run_pivots(eng, count: int) -> int:
+    """Exactly `count` more pivots; restarts from the start basis when the optimum is reached.  One mcf_solve call per
+    leg: the control block the solve leaves on the host answers stats() without another device round trip."""
     done = 0
     restarts = 0
     while done < count:
@@ -75,6 +99,28 @@ def run_pivots(eng, count: int):
             eng.reset()
             restarts += 1
     return restarts
+
+
+def kernel_name(mode: int, rule: int, incremental: bool) -> str:
+    if mode == 2:
+        return "k_solve_small"
+    if mode == 3:
+        return "k_solve_mid"
+    if mode == 1:
+        return f"k_price_rc<{1 if rule == 1 else 0},false,{'true' if incremental else 'false'}>"
+    return f"k_price<{1 if rule == 1 else 0},false>"
+
+
+def pmc_traffic(workload: str, kernel: str):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (rocprofv3 cannot run inside bench.py)."""
+    try:
+        table = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        hit = table.get(f"{workload}|{kernel}")
+        if hit:
+            return hit["bytes_per_launch"], hit["source"]
+    except Exception:
+        pass
+    return None, None
 
 
 def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pass: bool = True, full_sweeps: int = 1) -> dict:
@@ -96,20 +142,43 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     s1 = eng.stats()
+    mode = int(s1.get("pricing_mode", 0))
     pivots = s1["pivots"] - s0["pivots"] if restarts == 0 else steps
     arcs = s1["arcs_priced"] - s0["arcs_priced"] if restarts == 0 else steps * inst.m
     # arcs whose reduced cost was actually read: the grid sweeps count them per workgroup (kernel-per-phase path);
     # the single-workgroup loops read every arc they cover
-    swept = s1["arcs_swept"] - s0["arcs_swept"] if (restarts == 0 and s1.get("pricing_mode") == 1 and rule != 1) else arcs
+    swept = s1["arcs_swept"] - s0["arcs_swept"] if (restarts == 0 and mode == 1 and rule != 1) else arcs
+    incremental = bool(swept < 0.98 * arcs)
     out = {
         "workload": f"{inst.name}: {inst.n} nodes / {inst.m} arcs", "n": inst.n, "m": inst.m,
         "pivots": int(pivots), "seconds": dt, "pivots_per_sec": pivots / dt, "arcs_priced_per_sec": swept / dt,
-        "arcs_covered_per_sec": arcs / dt, "incremental_sweeps": bool(swept < 0.98 * arcs),
-        "ms_per_step": 1e3 * dt / max(pivots, 1), "restarts": restarts,
+        "arcs_covered_per_sec": arcs / dt, "incremental_sweeps": incremental,
+        "ms_per_step": 1e3 * dt / max(pivots, 1), "restarts": restarts, "pricing_mode": MODE_NAMES.get(mode, str(mode)),
     }
-    # dominant-kernel timing: HIP events on the engine's stream around every kernel of the same
-    # K pivots (second pass from the same start state, deterministic -> same pivots)
-    if profile_pass:
+    kname = kernel_name(mode, rule, incremental)
+    if mode in (2, 3) and s1["loop_launches"] > s0["loop_launches"]:
+        # one persistent workgroup ran the timed pivots: its launches were bracketed by HIP events on the engine's
+        # stream INSIDE the timed region.  Latency-bound: the bytes are SURVEY 8d's per-pivot figures.
+        launches = s1["loop_launches"] - s0["loop_launches"]
+        ms = (s1["loop_ms"] - s0["loop_ms"]) / launches
+        sweeps = pivots  # Dantzig / Devex: one pass per pivot (candidate list: fewer; arcs_priced already says so)
+        nbytes = ((17 if rule == 1 else 13) * arcs + 8 * (inst.n + 1) * sweeps
+                  + 20 * (s1["nodes_moved"] - s0["nodes_moved"]) + 28 * (s1["cycle_arcs"] - s0["cycle_arcs"])) / launches
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        traffic, src = pmc_traffic(workload, kname)
+        out["roofline"] = {
+            "kernel": kname, "bound": "hbm", "workload": out["workload"], "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src,
+            "bytes_per_launch": int(nbytes), "ms_per_launch": ms, "launches_in_timed_region": int(launches),
+            "pivots_per_launch": pivots / launches, "us_per_pivot_in_kernel": 1e3 * ms * launches / max(pivots, 1),
+            "note": "the timed region ran this ONE persistent workgroup (instance resident in LDS / one CU's caches): "
+                    "latency-bound by construction -- per-pivot latency is the figure of merit, the HBM fraction is ~0; "
+                    "bytes = SURVEY 8d per-pivot figures (13 B/arc priced + 8 B/node per sweep, 20 B/node moved, "
+                    "28 B/cycle arc)",
+        }
+    elif profile_pass and mode in (0, 1):
+        # dominant-kernel timing: HIP events on the engine's stream around every kernel of the same K pivots
+        # (second pass from the same start state, deterministic -> same pivots, same kernels: eager instead of graph)
         eng.close()
         eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, device=0,
                                profile=True, full_sweeps=full_sweeps)
@@ -121,67 +190,112 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         price_ms = (p1["price_ms"] - p0["price_ms"]) / launches
         pivot_ms = (p1["pivot_ms"] - p0["pivot_ms"]) / launches
         apply_ms = (p1["apply_ms"] - p0["apply_ms"]) / launches
-        bytes_per_launch = p1["price_bytes"]            # 13 B/arc + 8 B/node
         sweep_ms = eng.time_pricing(reps=50)            # back-to-back launches, no events in between
-        achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9
         out["kernel_ms"] = {"price": price_ms, "pivot": pivot_ms, "apply": apply_ms, "price_back_to_back": sweep_ms}
-        mode = p1.get("pricing_mode", 0)
-        kname = ("k_price_rc" if mode == 1 else "k_price") + ("<devex_block>" if rule == 1 else "<dantzig>")
-        out["pricing_mode"] = {0: "gather sweep", 1: "resident reduced costs", 2: "fused LDS loop",
-                               3: "persistent single-workgroup loop"}.get(mode, str(mode))
-        traffic, traffic_src = None, None
-        try:  # PMC traffic is collected offline (rocprofv3 --pmc passes) and committed under profiles/
-            table = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-            hit = table.get(f"{workload}|{out['pricing_mode']}")
-            if hit:
-                traffic, traffic_src = hit["bytes_per_launch"], hit["source"]
-        except Exception:
-            pass
+        per_pass = (p1["arcs_priced"] - p0["arcs_priced"]) / launches     # arcs one launch prices
+        if mode == 1:   # resident reduced costs: 8 B rc + 1 B state (+ 4 B Devex weight) per arc, 16 B per workgroup candidate
+            nbytes = (13 if rule == 1 else 9) * per_pass
+        else:           # gather sweep: SURVEY 8d's own figure
+            nbytes = (17 if rule == 1 else 13) * per_pass + 8 * (inst.n + 1)
+        achieved = nbytes / (price_ms * 1e-3) / 1e9
+        traffic, src = pmc_traffic(workload, kname)
+        survey = (17 if rule == 1 else 13) * per_pass + 8 * (inst.n + 1)
         out["roofline"] = {
             "kernel": kname, "bound": "hbm", "workload": out["workload"],
-            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": int(bytes_per_launch),
-            # the same launch time against the bytes the PMC counters saw (None when no PMC pass covers this workload)
-            "traffic_GBps": (traffic / (sweep_ms * 1e-3) / 1e9) if traffic else None,
-            "traffic_frac_of_peak": (traffic / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-            "ms_per_launch": sweep_ms, "ms_per_launch_in_pivot_loop": price_ms,
-            "note": "achieved = SURVEY section 8d algorithmic bytes (13 B/arc + 8 B/node) / launch time; the resident-rc "
-                    "sweep really moves 9 B/arc, so achieved can exceed the physical peak" if mode == 1 else
-                    "profiled pass runs the three-kernel path (the timed pass of small instances uses the fused LDS loop)",
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": min(achieved / HBM_PEAK_GBPS, 1.0),
+            "traffic": traffic, "traffic_source": src,
+            "traffic_GBps": (traffic / (price_ms * 1e-3) / 1e9) if traffic else None,
+            "traffic_frac_of_peak": (traffic / (price_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            "bytes_per_launch": int(nbytes), "ms_per_launch": price_ms, "ms_per_launch_back_to_back": sweep_ms,
+            "achieved_back_to_back": nbytes / (sweep_ms * 1e-3) / 1e9,
+            "working_set_fits_infinity_cache": bool(nbytes < 256 * 2 ** 20),
+            "survey_8d": {"bytes_per_launch": int(survey), "ratio_to_kernel_bytes": survey / max(nbytes, 1),
+                          "note": "SURVEY 8d prices the gather formulation (13 B/arc + 8 B/node); the resident-reduced-cost "
+                                  "sweep moves 9 B/arc and leaves the rest to k_update -- not a physical rate of this kernel"},
+            "note": "ms_per_launch: HIP events around every pricing launch of the same K pivots (profiled pass, eager "
+                    "launches); back_to_back: 50 launches between two events",
         }
     eng.close()
     return out
 
 
-def cpu_baseline(workload: str, budget_seconds: float = 12.0) -> dict:
-    """The oracle -- a single-threaded C restatement of the reference's algorithm -- on the same
-    workload, bounded to roughly `budget_seconds` of CPU work."""
+def host_cores() -> int:
+    """CPU threads this process may really use (affinity mask, cgroup quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(workload: str, budget_seconds: float = 10.0, max_threads: int = 64) -> dict:
+    """The oracle -- a C restatement of the reference's algorithm -- on the same workload, bounded to roughly
+    `budget_seconds` of wall time per leg: one thread, then every host core (independent solves side by side: the
+    reference has no parallel path, so throughput over cores is all a CPU can add)."""
+    import concurrent.futures as cf
+
     import oracle
 
     inst = make_instance(workload)
-    if inst.m <= 1 << 17:
-        t0 = time.perf_counter()
-        pivots = arcs = 0
-        solves = 0
-        while time.perf_counter() - t0 < budget_seconds:
-            r = oracle.solve_soa(inst, "dantzig", reference_order=False)
-            pivots += r["iterations"]
-            arcs += r["arcs_priced"]
-            solves += 1
-        dt = time.perf_counter() - t0
-        sample = f"{solves} complete Dantzig solves of {inst.name}"
-    else:
-        budget = 6
-        r = oracle.solve_soa(inst, "dantzig", reference_order=False, pivot_budget=budget)
+    small = inst.m <= 1 << 17
+
+    def one_thread(budget: float):
+        if small:
+            t0 = time.perf_counter()
+            pivots = arcs = solves = 0
+            while time.perf_counter() - t0 < budget:
+                r = oracle.solve_soa(inst, "dantzig", reference_order=False)
+                pivots += r["iterations"]
+                arcs += r["arcs_priced"]
+                solves += 1
+            return pivots, arcs, time.perf_counter() - t0, f"{solves} complete Dantzig solves of {inst.name}"
+        r = oracle.solve_soa(inst, "dantzig", reference_order=False, pivot_budget=6)
         per = r["seconds"] / max(r["iterations"], 1)
-        budget = int(max(6, min(400, budget_seconds / max(per, 1e-9))))
-        r = oracle.solve_soa(inst, "dantzig", reference_order=False, pivot_budget=budget)
-        pivots, arcs, dt = r["iterations"], r["arcs_priced"], r["seconds"]
-        sample = f"first {pivots} Dantzig pivots of {inst.name}"
-    return {"value": pivots / dt, "unit": "pivots/s", "arcs_priced_per_sec": arcs / dt, "cores": 1, "kind": "port",
-            "sample": sample, "host_cores_available": os.cpu_count(),
-            "note": "oracle/ref_simplex.c: the reference's float64 two-phase algorithm (per-pivot BFS rebuild + "
-                    "full Dantzig scan) restated in C, 1 thread; the pure-Python reference itself cannot travel"}
+        budget_p = int(max(6, min(400, budget / max(per, 1e-9))))
+        r = oracle.solve_soa(inst, "dantzig", reference_order=False, pivot_budget=budget_p)
+        return r["iterations"], r["arcs_priced"], r["seconds"], f"first {r['iterations']} Dantzig pivots of {inst.name}"
+
+    pivots, arcs, dt, sample = one_thread(budget_seconds)
+    out = {"value": pivots / dt, "unit": "pivots/s", "arcs_priced_per_sec": arcs / dt, "cores": 1, "kind": "port",
+           "sample": sample, "host_cores_available": host_cores(),
+           "note": "oracle/ref_simplex.c: the reference's float64 two-phase algorithm (per-pivot BFS rebuild + full "
+                   "Dantzig scan) restated in C; the pure-Python reference itself cannot travel to the GPU box"}
+    threads = min(host_cores(), max_threads if small else 8)   # (a 16 M-arc oracle instance holds ~2 GB per thread)
+    if threads > 1:
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(max_workers=threads) as pool:   # ctypes releases the GIL inside ref_solve
+            res = list(pool.map(lambda _: one_thread(budget_seconds * 0.6), range(threads)))
+        wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": sum(r[0] for r in res) / wall, "unit": "pivots/s",
+                            "arcs_priced_per_sec": sum(r[1] for r in res) / wall, "cores": threads,
+                            "sample": f"{threads} threads, each: {res[0][3]}"}
+    return out
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (nothing in this
+    process has touched the GPU) and relay rank 0's JSON line."""
+    import socket
+
+    import __graft_entry__ as ge
+
+    ge.build_hip()   # once, before the ranks start
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -191,12 +305,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--rule", default="dantzig", choices=["dantzig", "devex", "candidate_list"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = arcs per GPU fixed (the instance grows with N); strong = the BASELINE instance fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-point", action="store_true")
     args = ap.parse_args()
     rule = {"dantzig": 0, "devex": 1, "candidate_list": 2}[args.rule]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     if args.gpus > 1 or world > 1 or os.environ.get("MCF_BENCH_FORCE_DIST") == "1":  # env: rehearse the sharded path on 1 GPU
         from network_flow_solver_amd import distributed
 
@@ -213,16 +331,17 @@ def main():
         "value": head["arcs_priced_per_sec"], "unit": "arcs/s", "pivots_per_sec": head["pivots_per_sec"],
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": head["workload"],
-                   "pricing": {0: "full-scan Dantzig", 1: "block-search Devex", 2: "candidate list"}[rule],
+        "config": {"workload": head["workload"], "pricing": RULE_NAMES[rule],
                    "step": "one pivot (price + ratio test + tree/potential update)", "parallelism": "1 GPU",
+                   "engine_path": head["pricing_mode"],
                    "sweeps": "full (every arc priced every pivot)",
                    "restarts_in_timed_region": head["restarts"]},
         "roofline": head.get("roofline"), "kernel_ms": head.get("kernel_ms"),
         "reference_published": {"pivots_per_sec": 52, "instance": "netgen_8_08a (real file)", "hardware": "unstated CPU",
                                 "source": "benchmarks/results/after-iteration-fix.json:89-98"},
     }
-    if not args.no_hbm_point and workload == "netgen_8_08a":
+    default_run = not args.no_hbm_point and workload == "netgen_8_08a"
+    if default_run:
         big = measure_single("netgen_1m_16m", min(args.steps, 200), min(args.warmup, 20), rule)
         line["hbm_point"] = {
             "workload": big["workload"], "value": big["arcs_priced_per_sec"], "unit": "arcs/s",
@@ -244,7 +363,6 @@ def main():
             "arcs_read_per_sec": inc["arcs_priced_per_sec"], "arcs_covered_per_sec": inc["arcs_covered_per_sec"],
             "note": "a pricing workgroup whose arcs did not change since it last swept them keeps its candidate; the entering "
                     "arc is still the arg-max over all arcs (pivot sequence identical, asserted by the GPU tests)"}
-    if not args.no_hbm_point and workload == "netgen_8_08a":
         # the other single-GPU-runnable BASELINE.json configs, measured the same way (no profiled pass)
         pts = []
         for wl, r, label in (("gridgen_8_14a", 1, "configs[2]: gridgen_8_14a, block-search Devex"),
@@ -253,12 +371,20 @@ def main():
             m_ = measure_single(wl, 2000, 200, r, profile_pass=False, full_sweeps=0)  # engine defaults
             pts.append({"config": label, "workload": m_["workload"], "pivots_per_sec": m_["pivots_per_sec"],
                         "arcs_priced_per_sec": m_["arcs_priced_per_sec"], "arcs_covered_per_sec": m_["arcs_covered_per_sec"],
-                        "ms_per_step": m_["ms_per_step"], "steps": m_["pivots"]})
+                        "ms_per_step": m_["ms_per_step"], "steps": m_["pivots"], "engine_path": m_["pricing_mode"]})
         line["config_points"] = pts
+        # beyond the Infinity Cache: 64 M arcs = 604 MB of reduced costs + states per sweep
+        _instances.clear()
+        far = measure_single("netgen_4m_64m", 40, 8, rule)
+        line["hbm_point_beyond_infinity_cache"] = {
+            "workload": far["workload"], "value": far["arcs_priced_per_sec"], "unit": "arcs/s",
+            "pivots_per_sec": far["pivots_per_sec"], "ms_per_step": far["ms_per_step"], "steps": far["pivots"],
+            "roofline": far.get("roofline"), "kernel_ms": far.get("kernel_ms")}
+        _instances.clear()
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(workload)
         if "hbm_point" in line:
-            line["hbm_point"]["cpu_baseline"] = cpu_baseline("netgen_1m_16m", budget_seconds=15.0)
+            line["hbm_point"]["cpu_baseline"] = cpu_baseline("netgen_1m_16m", budget_seconds=10.0)
     print(json.dumps(line))
 
 

@@ -122,6 +122,9 @@ typedef struct mcf_stats {
     int64_t cycle_scans;      /* pivots whose cycle was completed by the position-space scan */
     int64_t scan_rounds;      /* chunk iterations of those scans */
     int64_t arcs_swept;       /* arcs whose reduced cost the grid sweeps actually read (<= arcs_priced with incremental pricing) */
+    double loop_ms;           /* persistent pivot loops (pricing_mode 2, and 3 outside a graph): summed kernel durations, by HIP
+                                 events on the engine's stream around every launch */
+    int64_t loop_launches;    /* ... and the number of launches (one launch runs many pivots) */
 } mcf_stats;
 
 /* Called from mcf_solve every cb_interval pivots (simplex.py:1143-1154).

@@ -191,7 +191,8 @@ struct McfCtx {
     int32_t wreset;            // hand-over decide -> finish: reset the listed weights to 1
     int32_t devex_cyclic;      // 1: the block advances after every pivot; 0: stay on a block until it is empty (the reference)
     int32_t max_granules;      // the tuner never grows a block beyond this (bounds the arcs one pricing pass reads)
-    int32_t pad1;
+    int32_t limit_checked;     // status == MCF_PIVOT_LIMIT was confirmed on the device: an eligible arc is left
+                               // (simplex.py:1678-1699 re-prices once at the budget to tell optimal from iteration_limit)
     // ---- candidate-list state
     int32_t minor_left;        // > 0: the next pass re-prices the candidate list instead of sweeping
     int32_t minor_cap;         // minor pivots allowed per full sweep

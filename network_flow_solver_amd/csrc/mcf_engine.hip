@@ -516,8 +516,16 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
 //   candidate list:               the launch ends when a full sweep is due (k_price_rc over the whole grid builds
 //                                 the next list); `fresh` says such a sweep ran right before this launch.
 
+// `arm`: take the pivot cap from the kernel argument (what k_ctl does for the other paths: one launch less per call;
+// only for launches that are not replayed from a captured graph, whose arguments are frozen).
+__device__ __forceinline__ void arm_ctx(McfCtx* c, int64_t cap) {
+    c->max_pivots = cap;
+    c->limit_checked = 0;
+    if (c->status == MCF_PIVOT_LIMIT && c->pivots < cap) c->status = MCF_RUNNING;
+}
+
 __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t rule, const McfCand* __restrict__ cand,
-                                                              int ncand, int fresh, int max_iters) {
+                                                              int ncand, int fresh, int max_iters, int arm, int64_t cap) {
     __shared__ PivotShared S;
     __shared__ int32_t s_gran[MCF_NUM_BUCKETS][MCF_GRANULES + 1];  // Devex: the granule table (blocks move and resize under the tuner)
     __shared__ int32_t s_lo[MCF_NUM_BUCKETS], s_hi[MCF_NUM_BUCKETS];  // other rules: the whole buckets
@@ -534,6 +542,8 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
         s_lo[threadIdx.x] = (int32_t)g.bucket_off[threadIdx.x];
         s_hi[threadIdx.x] = (int32_t)g.bucket_off[threadIdx.x + 1];
     }
+    __syncthreads();
+    if (arm && threadIdx.x == 0) arm_ctx(&S.ctx, cap);
     __syncthreads();
     McfView v = g;
     v.ctx = &S.ctx;
@@ -644,6 +654,21 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
         if (threadIdx.x == 0) S.ctx.apply = 0;
     }
     __syncthreads();
+    // at the budget: is any arc still eligible?  (simplex.py:1678-1699; saves the host a pricing pass + three syncs)
+    if (S.ctx.status == MCF_PIVOT_LIMIT && !S.ctx.limit_checked) {
+        __shared__ int s_any;
+        if (threadIdx.x == 0) s_any = 0;
+        __syncthreads();
+        int any = 0;
+        for (int64_t i = threadIdx.x; i < g.m && !any; i += kPivotThreads) {
+            const int64_t st = g.state[i];
+            if (st != 0 && -st * g.rcache[i] > 0) any = 1;
+        }
+        if (any) s_any = 1;
+        __syncthreads();
+        if (threadIdx.x == 0) { if (s_any) S.ctx.limit_checked = 1; else S.ctx.status = MCF_OPTIMAL; }
+        __syncthreads();
+    }
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&S.ctx)[threadIdx.x];
 #ifdef MCF_STAMPS
     if (threadIdx.x == 0) for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i];
@@ -756,7 +781,7 @@ __device__ __forceinline__ void copy_words(void* dst, const void* src, uint32_t 
 #endif
 
 __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallLayout L, int32_t rule,
-                                                                McfCand* __restrict__ list) {
+                                                                McfCand* __restrict__ list, int64_t cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef MCF_STAMPS
     unsigned long long stamps_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -810,6 +835,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     STAMP(0);
 
     McfCtx* c = v.ctx;
+    if (threadIdx.x == 0) arm_ctx(c, cap);  // (what k_ctl does for the other paths; visible after the barrier below)
     // Devex: the host-made granule table in LDS (blocks move and resize under the tuner); other rules: whole buckets
     __shared__ int32_t s_gran[MCF_NUM_BUCKETS][MCF_GRANULES + 1];
     const bool devex = rule == MCF_RULE_DEVEX_BLOCK && g.dx;
@@ -936,6 +962,19 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         STAMP(5);
     }
 
+    // at the budget: is any arc still eligible?  (simplex.py:1678-1699; saves the host a pricing pass + three syncs)
+    if (c->status == MCF_PIVOT_LIMIT && !c->limit_checked) {
+        __shared__ int s_any;
+        if (threadIdx.x == 0) s_any = 0;
+        __syncthreads();
+        int any = 0;
+        for (int64_t i = threadIdx.x; i < g.m && !any; i += kSmallThreads)
+            if (v.state[i] && mcf_violation(v, i) > 0) any = 1;
+        if (any) s_any = 1;
+        __syncthreads();
+        if (threadIdx.x == 0) { if (s_any) c->limit_checked = 1; else c->status = MCF_OPTIMAL; }
+        __syncthreads();
+    }
     copy_words(g.state, smem + L.state, m_padb);
     if (g.weight) copy_words(g.weight, smem + L.weight, m_pad4);
     copy_words(g.arcw, smem + L.arcw, arcw_b);
@@ -960,6 +999,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
 // ------------------------------------------------------------------ k_ctl: (re)arm the control block
 __global__ void k_ctl(McfCtx* c, int64_t max_pivots, int resume) {
     c->max_pivots = max_pivots;
+    c->limit_checked = 0;
     if (resume && c->status == MCF_PIVOT_LIMIT && c->pivots < max_pivots) c->status = MCF_RUNNING;
 }
 
@@ -1016,11 +1056,13 @@ struct mcf_handle {
     int graph_batch = 0;
     // profiling events
     std::vector<hipEvent_t> events;
+    hipEvent_t loop_ev[2] = {nullptr, nullptr};  // around every launch of a persistent pivot loop
     // bookkeeping
     mcf_stats stats{};
     int64_t total_cap = 0;
     std::string err;
     bool solved_once = false;
+    bool ctx_current = false;  // *h_ctx equals the device control block (no kernel was enqueued since it was read)
 };
 
 namespace {
@@ -1114,6 +1156,7 @@ int upload_image(mcf_handle* h) {
     h->stats.price_bytes = (h->opt.rule == MCF_RULE_DEVEX_BLOCK ? 17 : 13) * h->priced_per_pass + 8 * (int64_t)im.n_nodes;
     h->total_cap = 0;
     h->solved_once = false;
+    h->ctx_current = true;  // *h_ctx was just copied to the device
     return MCF_OK;
 }
 
@@ -1155,7 +1198,8 @@ void launch_apply(mcf_handle* h, hipStream_t s) {
 // One pivot slot.  Candidate-list rule: only every (minor_cap + 1)-th slot carries a pricing launch;
 // the slots in between go straight to k_pivot, which re-prices the list (a pricing launch there
 // would be a no-op anyway -- this just saves its launch boundary).
-void launch_pivot_triplet(mcf_handle* h, hipStream_t s, int slot = 0) {
+// arm_cap >= 0 (persistent loop outside a graph): the kernel takes the pivot cap from its argument, no k_ctl launch
+void launch_pivot_triplet(mcf_handle* h, hipStream_t s, int slot = 0, int64_t arm_cap = -1) {
     const int32_t rule = h->opt.rule;
     if (h->mid) {
         // candidate list: one grid sweep (a no-op while the list is live), then the persistent loop runs the major
@@ -1163,7 +1207,8 @@ void launch_pivot_triplet(mcf_handle* h, hipStream_t s, int slot = 0) {
         const bool listing = rule == MCF_RULE_CANDIDATE_LIST;
         if (listing) launch_price(h, s, h->view, rule, 1);
         hipLaunchKernelGGL(k_solve_mid, dim3(1), dim3(kPivotThreads), 0, s, h->view, rule, h->d_cand, h->price_blocks,
-                           listing ? 1 : 0, listing ? mcf_minor_cap(h->price_blocks) + 2 : (1 << 22));
+                           listing ? 1 : 0, listing ? mcf_minor_cap(h->price_blocks) + 2 : (1 << 22), arm_cap >= 0 ? 1 : 0,
+                           arm_cap >= 0 ? arm_cap : (int64_t)0);
         return;
     }
     int have_sweep = 1;
@@ -1220,13 +1265,17 @@ int run_batch_profiled(mcf_handle* h, int batch) {
 int read_ctx(mcf_handle* h, hipStream_t s) {
     HIP_TRY(h, hipMemcpyAsync(h->h_ctx, h->d_ctx, sizeof(McfCtx), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    h->ctx_current = true;
     return MCF_OK;
 }
+// the host copy of the control block, refreshed only when something ran since it was last read
+int sync_ctx(mcf_handle* h, hipStream_t s) { return h->ctx_current ? MCF_OK : read_ctx(h, s); }
 
 void free_all(mcf_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->loop_ev) if (e) (void)hipEventDestroy(e);
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
@@ -1472,6 +1521,7 @@ int mcf_set_max_pivots(mcf_handle* h, int64_t max_total_pivots) {
     // the caller enqueues the pivots on a stream of its own: make the new cap visible first
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total_cap = max_total_pivots;
+    h->ctx_current = false;
     return MCF_OK;
 }
 
@@ -1487,7 +1537,7 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t m = h->im.m, n = h->im.n;
     if (max_pivots < 0) max_pivots = 20 * (m + n) > 100 ? 20 * (m + n) : 100;  // simplex.py:1470
-    int rc = read_ctx(h, h->stream);
+    int rc = sync_ctx(h, h->stream);
     if (rc) return rc;
     const int64_t start = h->h_ctx->pivots;
     const int64_t final_cap = start + max_pivots;
@@ -1509,23 +1559,36 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
             const int64_t next_cb = start + (done / cb_interval + 1) * cb_interval;
             if (next_cb < cap) cap = next_cb;
         }
-        hipLaunchKernelGGL(k_ctl, dim3(1), dim3(1), 0, h->stream, h->d_ctx, cap, 1);
+        // the persistent loops outside a graph take the cap as a kernel argument; the other paths re-arm with k_ctl
+        const bool arm_in_kernel = h->small || (h->mid && !graph && !h->opt.profile);
+        if (!arm_in_kernel) hipLaunchKernelGGL(k_ctl, dim3(1), dim3(1), 0, h->stream, h->d_ctx, cap, 1);
+        h->ctx_current = false;
         // pivot until the device reports something other than "still running"
         for (;;) {
+            const bool timed_loop = arm_in_kernel;  // one kernel = many pivots: its duration is the per-launch figure bench.py reports
+            if (timed_loop) {
+                if (!h->loop_ev[0]) { HIP_TRY(h, hipEventCreate(&h->loop_ev[0])); HIP_TRY(h, hipEventCreate(&h->loop_ev[1])); }
+                HIP_TRY(h, hipEventRecord(h->loop_ev[0], h->stream));
+            }
             if (h->small)
                 hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(kSmallThreads), h->small_layout.total, h->stream, h->view,
-                                   h->small_layout, h->opt.rule, h->d_cand);
+                                   h->small_layout, h->opt.rule, h->d_cand, cap);
             else {
                 // eager launches need not run past the cap (a replayed graph has a fixed length: its surplus slots early-exit)
                 const int64_t left = cap - h->h_ctx->pivots;
                 const int slots = h->mid ? batch : (int)(left < 1 ? 1 : (left < batch ? left : batch));
                 if (h->opt.profile) { rc = run_batch_profiled(h, slots); if (rc) return rc; }
                 else if (graph) HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
-                else for (int i = 0; i < slots; ++i) launch_pivot_triplet(h, h->stream, i);
+                else for (int i = 0; i < slots; ++i) launch_pivot_triplet(h, h->stream, i, arm_in_kernel ? cap : (int64_t)-1);
             }
+            if (timed_loop) HIP_TRY(h, hipEventRecord(h->loop_ev[1], h->stream));
             HIP_TRY(h, hipGetLastError());
             rc = read_ctx(h, h->stream);
             if (rc) return rc;
+            if (timed_loop) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, h->loop_ev[0], h->loop_ev[1]) == hipSuccess) { h->stats.loop_ms += ms; h->stats.loop_launches += 1; }
+            }
             h->stats.batches += 1;
             if (h->h_ctx->status != MCF_RUNNING) break;
         }
@@ -1539,8 +1602,9 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
         }
         stop = true;
     }
-    if (h->h_ctx->status == MCF_PIVOT_LIMIT) {
+    if (h->h_ctx->status == MCF_PIVOT_LIMIT && !h->h_ctx->limit_checked) {
         // simplex.py:1678-1699: at the budget, price once more to tell optimal from iteration_limit
+        // (the persistent loops have done that on the device: limit_checked)
         int64_t arc = -1, key = 0; int32_t dir = 0;
         rc = mcf_price_once(h, h->opt.rule == MCF_RULE_DEVEX_BLOCK ? MCF_RULE_DANTZIG_FULL : h->opt.rule, 0, m, &arc, &dir, &key);
         if (rc) return rc;
@@ -1560,7 +1624,7 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
                    int8_t* in_tree, mcf_stats* stats) {
     if (!h) return MCF_E_BAD_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
-    int rc = read_ctx(h, h->stream);
+    int rc = sync_ctx(h, h->stream);
     if (rc) return rc;
     const McfHostImage& im = h->im;
     // the flow copy (16 B per arc) is only made when something derived from it is asked for
@@ -1674,6 +1738,7 @@ int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev) {
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int32_t rule = h->opt.rule;
+    h->ctx_current = false;
     launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG);
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kReduceThreads), 0, s, h->d_cand, h->price_blocks,
                        reinterpret_cast<McfCand*>(cand_out_dev));
@@ -1685,6 +1750,7 @@ int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int
     if (!h || !cands_dev || ncand < 1) return MCF_E_BAD_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    h->ctx_current = false;
     launch_k_pivot(h, s, reinterpret_cast<const McfCand*>(cands_dev), ncand, h->opt.rule, 1);
     launch_apply(h, s);
     HIP_TRY(h, hipGetLastError());
@@ -1694,7 +1760,7 @@ int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int
 int mcf_poll(mcf_handle* h, void* stream, int32_t* status_or_running, int64_t* pivots) {
     if (!h) return MCF_E_BAD_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
-    const int rc = read_ctx(h, static_cast<hipStream_t>(stream));
+    const int rc = sync_ctx(h, static_cast<hipStream_t>(stream));
     if (rc) return rc;
     if (h->h_ctx->status == MCF_INTERNAL_ERROR) { h->err = "internal error: preorder permutation did not close"; return MCF_E_INTERNAL; }
     if (status_or_running) {

@@ -170,21 +170,27 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
     rule = {"dantzig": 0, "devex": 1, "candidate_list": 2}[args.rule]
     workload = args.workload or "netgen_8_08a"
 
+    strong = getattr(args, "scaling", "weak") == "strong"
+
     def measure(wl: str, steps: int, warmup: int) -> dict:
         fam, n1, m1 = workloads[wl]
-        # weak scaling: per-GPU arcs fixed, the instance grows with the number of GPUs
+        # weak scaling: per-GPU arcs fixed, the instance grows with the number of GPUs;
+        # strong scaling: the BASELINE instance itself, cut into `world` shards
+        scale = 1 if strong else world
+        tag = f"{wl}(synthetic,x{scale})"
         if fam == "gridgen":
-            inst = generators.gridgen_style(n1 * world, m1, seed=1, name=f"{wl}(synthetic,x{world})")
+            inst = generators.gridgen_style(n1 * scale, m1, seed=1, name=tag)
         elif fam == "goto":
-            inst = generators.goto_style(n1 * world, m1, seed=1, name=f"{wl}(synthetic,x{world})")
+            inst = generators.goto_style(n1 * scale, m1, seed=1, name=tag)
         else:
-            inst = generators.netgen_style(n1 * world, m1 * world, seed=1, name=f"{wl}(synthetic,x{world})")
+            inst = generators.netgen_style(n1 * scale, m1 * scale, seed=1, name=tag)
         eng = HipShardEngine(inst, rule, rank, world, local_rank, full_sweeps=1)  # value counts every arc of every sweep: so price them all
         force = os.environ.get("MCF_BENCH_FORCE_DIST") == "1"  # 1-GPU rehearsal: still issue the collective
         loop = PivotLoop(eng, dist, world, batch=32, always_gather=force,
                          use_graph=os.environ.get("MCF_DIST_GRAPH", "1") == "1")  # MCF_DIST_GRAPH=0: eager loop
         loop.run(warmup)
         _, p0 = eng.poll()
+        a0 = eng.eng.stats()["arcs_priced"]
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -196,32 +202,42 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         pivots = p1 - p0
+        arcs = eng.eng.stats()["arcs_priced"] - a0          # whole-job accounting: every pass counts the arcs of ALL shards
         sweep_ms = eng.eng.time_pricing(reps=20)
         shard_arcs = inst.m // world
-        bytes_per_launch = 13 * shard_arcs + 8 * (inst.n + 1)
+        # the kernel that runs is the resident-reduced-cost sweep over the rank's shard: 8 B rc + 1 B state per arc
+        # (+ 4 B Devex weight); SURVEY 8d's gather figure (13 B/arc + 8 B/node) is kept beside it for comparison
+        per_arc = 13 if rule == 1 else 9
+        bytes_per_launch = per_arc * shard_arcs
         achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9
         eng.close()
         return {"workload": f"{inst.name}: {inst.n} nodes / {inst.m} arcs, {shard_arcs} arcs per GPU", "pivots": pivots,
-                "seconds": dt, "pivots_per_sec": pivots / dt, "arcs_priced_per_sec": pivots * inst.m / dt,
+                "seconds": dt, "pivots_per_sec": pivots / dt,
+                "arcs_priced_per_sec": arcs / dt,
                 "ms_per_step": 1e3 * dt / max(pivots, 1), "completed": status == 2,
                 "pivot_loop": "captured graph" if loop.graph is not None else "eager", "graph_error": loop.graph_error,
-                "roofline": {"kernel": "k_price (per-rank shard)", "bound": "hbm", "achieved": achieved,
-                             "peak": hbm_peak_gbps, "unit": "GB/s", "frac": achieved / hbm_peak_gbps, "traffic": None,
-                             "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": sweep_ms}}
+                "roofline": {"kernel": f"k_price_rc<{1 if rule == 1 else 0},false,false> (per-rank shard)", "bound": "hbm",
+                             "achieved": achieved, "peak": hbm_peak_gbps, "unit": "GB/s",
+                             "frac": min(achieved / hbm_peak_gbps, 1.0), "traffic": None,
+                             "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": sweep_ms,
+                             "working_set_fits_infinity_cache": bool(bytes_per_launch < 256 * 2 ** 20),
+                             "survey_8d": {"bytes_per_launch": int((17 if rule == 1 else 13) * shard_arcs + 8 * (inst.n + 1))},
+                             "note": "back-to-back launches between two HIP events on the engine's stream; traffic: no PMC "
+                                     "pass exists for the sharded sweep (the 1-GPU passes are in profiles/pmc_traffic.json)"}}
 
     head = measure(workload, args.steps, args.warmup)
     line = {
         "metric": "pivots/sec + arcs-priced/sec (value = arcs-priced/sec; pivots_per_sec alongside) on netgen_8-style DIMACS",
         "value": head["arcs_priced_per_sec"], "unit": "arcs/s", "pivots_per_sec": head["pivots_per_sec"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": head["workload"], "pricing": {0: "full-scan Dantzig", 1: "block-search Devex", 2: "candidate list"}[rule],
                    "step": "one pivot (sharded price + 16 B all-gather + replicated tree/potential update)",
                    "parallelism": f"arc-sharded x{world}, replicated tree, 1 RCCL all-gather per pivot",
                    "pivot_loop": head["pivot_loop"], "graph_error": head["graph_error"]},
         "roofline": head["roofline"],
     }
-    if not args.no_hbm_point and workload == "netgen_8_08a":
+    if not args.no_hbm_point and workload == "netgen_8_08a" and not strong:
         big = measure("netgen_8_18a" if "netgen_8_18a" in workloads else "netgen_8_16a", min(args.steps, 200), min(args.warmup, 20))
         line["hbm_point"] = {k: big[k] for k in ("workload", "pivots_per_sec", "ms_per_step", "roofline", "pivot_loop")}
         line["hbm_point"]["value"] = big["arcs_priced_per_sec"]

@@ -516,8 +516,36 @@ def test_devex_kernel_matches_reference_block_selection(gpu_engine_module, which
     assert checked >= 10
     if which.startswith("tie_rich"):
         assert same_dir_ties > 0                                    # the tie rules were really exercised
-    if which in ("tie_rich_3",):
-        assert cross_dir_ties > 0
+
+
+def test_devex_forward_backward_tie_prefers_the_backward_arc(gpu_engine_module):
+    """A forward and a backward candidate with the same merit: the reference's vectorised selection takes the
+    backward one (forward wins only when strictly greater, simplex.py:596) although its index is higher; the
+    Dantzig loop takes the first index (simplex_pricing.py:126).  The state is installed with mcf_set_basis:
+    tree 3 -> 2 -> 1 -> 0 (zero-cost-1 arcs pointing at the root), arc 3 = (3, 0) at its lower bound with
+    rc = -2, arc 4 = (0, 3) at its upper bound with rc = +2."""
+    e = gpu_engine_module
+    tail = np.array([1, 2, 3, 3, 0], np.int32)
+    head = np.array([0, 1, 2, 0, 3], np.int32)
+    cost = np.array([1, 1, 1, 1, -1], np.int64)
+    cap = np.array([-1, -1, -1, 5, 2], np.int64)
+    supply = np.zeros(4, np.int64)
+    inst = generators.ArcSoA(4, tail, head, cost, cap, supply, "fwd_bwd_tie")
+    for kw in ({}, {"fused": False}, {"fused": False, "mid_loop": -1}, {"fused": False, "resident_rc": False}):
+        with e.McfEngine(4, tail, head, cost, cap, supply, rule=1, **kw) as eng:
+            assert eng.set_basis([1, 1, 1, 0, 0], [0, 0, 0, 0, 1])
+            res, tree, w = eng.result(), eng.tree(), eng.weights()
+            assert res.flow.tolist() == [2, 2, 2, 0, 2] and (w == 1).all()
+            rc = cost + tree["pi"][tail] - tree["pi"][head]
+            assert rc.tolist() == [0, 0, 0, -2, 2] and tree["state"].tolist() == [0, 0, 0, 1, -1]
+            exp = _devex_block_reference(inst, res, tree, w, 0, 5)
+            assert exp == (4, -1, 4.0)
+            got = eng.price_once(1)
+            assert (got[0], got[1]) == (4, -1) and np.int64(got[2]) == np.float64(4.0).view(np.int64)
+            assert eng.price_once(1, 0, 4)[:2] == (3, 1)              # without the backward arc in range
+            assert eng.price_once(0)[:2] == (3, 1)                     # Dantzig: first index among equal violations
+            eng.solve()
+            assert eng.result().status == "optimal" and eng.result().objective == 0
 
 
 def test_devex_pivot_counts_close_to_the_reference(gpu_engine_module):
