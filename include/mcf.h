@@ -178,6 +178,19 @@ int mcf_set_basis(mcf_handle* h, const int8_t* in_tree, const int8_t* at_upper);
  * `stream` is a hipStream_t (0 = default stream).  Nothing here synchronises. */
 int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev);
 int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int32_t ncand);
+/* Candidate-list rule over several ranks -- the amortisation lever of SURVEY.md section 8e: ONE collective per
+ * (minor_cap + 1) pivots instead of one per pivot.
+ *   mcf_shard_info          list_len = candidates one sweep of this handle leaves (one per pricing workgroup);
+ *                           minor_cap = pivots that may re-price a list before the next sweep (simplex_pricing.py:398-400)
+ *   mcf_enqueue_price_list  sweep the shard; cands_out (device, list_len x {key, packed arc id}) <- its candidates
+ *   <all-gather of the lists, by the caller>
+ *   mcf_enqueue_pivots      `count` pivots on the gathered list: the first takes the sweep's keys, the others re-price
+ *                           the listed arcs against the current potentials (minor iterations, simplex_pricing.py:419-456)
+ * With shard_count > 1 a handle patches the resident reduced costs of its own shard only (1 / shard_count of the
+ * update work); listed arcs of other shards are re-priced from the replicated potentials. */
+int mcf_shard_info(mcf_handle* h, int32_t* list_len, int32_t* minor_cap);
+int mcf_enqueue_price_list(mcf_handle* h, void* stream, int64_t* cands_out_dev);
+int mcf_enqueue_pivots(mcf_handle* h, void* stream, const int64_t* cands_dev, int32_t ncand, int32_t count);
 /* Read the control block (synchronises `stream`): status (MCF_ST_* or -1 = still running). */
 int mcf_poll(mcf_handle* h, void* stream, int32_t* status_or_running, int64_t* pivots);
 int mcf_set_max_pivots(mcf_handle* h, int64_t max_total_pivots);

@@ -17,6 +17,7 @@ from .data import (
     Node,
     ProgressCallback,
     ProgressInfo,
+    SoAProblem,
     SolverOptions,
     build_problem,
 )
@@ -34,7 +35,7 @@ from .simplex import NetworkSimplex
 from .solver import load_problem, save_result, solve_min_cost_flow
 
 __all__ = [
-    "Arc", "Basis", "FlowResult", "NetworkProblem", "Node", "ProgressCallback", "ProgressInfo", "SolverOptions",
+    "Arc", "Basis", "FlowResult", "NetworkProblem", "Node", "ProgressCallback", "ProgressInfo", "SoAProblem", "SolverOptions",
     "build_problem", "parse_dimacs_file", "parse_dimacs_soa", "parse_dimacs_string", "InfeasibleProblemError",
     "InvalidProblemError", "IterationLimitError", "NetworkSolverError", "NumericalInstabilityError",
     "SolverConfigurationError", "UnboundedProblemError", "NetworkSimplex", "load_problem", "save_result",

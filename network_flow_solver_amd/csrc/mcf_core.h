@@ -256,6 +256,8 @@ struct McfView {
     McfSeg* seg;            // [2*n_nodes + 2] scratch
     McfCtx* ctx;
     // ---- resident reduced costs (large instances; nullptr = price by gathering potentials)
+    int32_t rc_partial;     // 1: a sharded handle keeps rcache exact for ITS OWN shard only (the patch walks a per-rank
+                            // adjacency: 1/G of the work); single arcs outside the sweep are then priced from the potentials
     int64_t* rcache;        // [m_pad] rc of every arc under the current potentials, engine order
     const int64_t* adj_off; // [n_nodes] CSR over real nodes: entries of node u are adj[adj_off[u] .. adj_off[u+1])
     const int64_t* adj;     // [2m] (other end point << 32) | (engine arc << 1) | (1 when u is the arc's tail)
@@ -414,7 +416,7 @@ MCF_HD int64_t mcf_minor_key(const McfView& v, int64_t packed_arc) {
     const int64_t e = packed_arc & 0xffffffff;
     const int64_t s = v.state[e];
     if (s == 0) return 0;
-    const int64_t rc = v.rcache ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
+    const int64_t rc = (v.rcache && !v.rc_partial) ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
     const int64_t viol = -s * rc;
     return viol > 0 ? viol : 0;
 }
@@ -521,7 +523,7 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
     const int32_t first = s > 0 ? v.tail[e] : v.head[e];
     const int32_t second = s > 0 ? v.head[e] : v.tail[e];
     // exact reduced cost of the entering arc (the Devex key is a merit, not a violation)
-    const int64_t rc = v.rcache ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
+    const int64_t rc = (v.rcache && !v.rc_partial) ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
 
     c->pv_e = e; c->pv_s = s; c->pv_first = first; c->pv_second = second; c->pv_rc = rc;
     const McfArcW ae = v.arcw[e];  // one 16-byte load: capacity for the ratio test, flow for the store-only update

@@ -1439,7 +1439,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     // resident reduced costs for everything that does not take the fused LDS path
     h->rcached = !h->small && !opt.no_rcache && im.m > 0;
     if (h->rcached) {
-        mcf_build_rcache(h->im);
+        mcf_build_rcache(h->im, h->shard, h->shards);
+        v.rc_partial = h->shards > 1 ? 1 : 0;
         if ((e = dalloc(&h->d_rcache, im.m_pad)) != hipSuccess) return fail("hipMalloc rcache", e);
         if ((e = dalloc(&h->d_adj_off, im.adj_off.size())) != hipSuccess) return fail("hipMalloc adj_off", e);
         if ((e = dalloc(&h->d_adj, im.adj.size())) != hipSuccess) return fail("hipMalloc adj", e);
@@ -1450,7 +1451,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         const int64_t rb = ((int64_t)im.n_nodes + 15) / 16;  // one 16-lane group per node of the largest possible T2
         h->rcupd_blocks = (int)(rb < kMaxRcupdBlocks ? (rb > 0 ? rb : 1) : kMaxRcupdBlocks);
     } else {
-        v.rcache = nullptr; v.adj_off = nullptr; v.adj = nullptr;
+        v.rcache = nullptr; v.adj_off = nullptr; v.adj = nullptr; v.rc_partial = 0;
     }
     // persistent single-workgroup loop: the tree work of one pivot must be small enough for one CU, and so must
     // the arcs it prices per pivot (a Devex block / the whole arc list for Dantzig; the candidate list's full
@@ -1757,6 +1758,39 @@ int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int
     return MCF_OK;
 }
 
+int mcf_shard_info(mcf_handle* h, int32_t* list_len, int32_t* minor_cap) {
+    if (!h) return MCF_E_BAD_ARG;
+    if (list_len) *list_len = h->price_blocks;
+    if (minor_cap) *minor_cap = mcf_minor_cap(h->price_blocks);
+    return MCF_OK;
+}
+
+int mcf_enqueue_price_list(mcf_handle* h, void* stream, int64_t* cands_out_dev) {
+    if (!h || !cands_out_dev) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int32_t rule = h->opt.rule;
+    h->ctx_current = false;
+    // the pricing grid writes one candidate per workgroup straight into the caller's buffer (price_blocks entries);
+    // candidate-list rule: a no-op while minor iterations are pending, so the buffer keeps the live list
+    launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG, reinterpret_cast<McfCand*>(cands_out_dev));
+    HIP_TRY(h, hipGetLastError());
+    return MCF_OK;
+}
+
+int mcf_enqueue_pivots(mcf_handle* h, void* stream, const int64_t* cands_dev, int32_t ncand, int32_t count) {
+    if (!h || !cands_dev || ncand < 1 || count < 1) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    h->ctx_current = false;
+    for (int i = 0; i < count; ++i) {  // slot 0 takes the fresh list, the others re-price it (minor iterations)
+        launch_k_pivot(h, s, reinterpret_cast<const McfCand*>(cands_dev), ncand, h->opt.rule, i == 0 ? 1 : 0);
+        launch_apply(h, s);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return MCF_OK;
+}
+
 int mcf_poll(mcf_handle* h, void* stream, int32_t* status_or_running, int64_t* pivots) {
     if (!h) return MCF_E_BAD_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1872,6 +1906,18 @@ int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident) {
     if (h->rcached) {
         std::vector<int64_t> rc(im.m_pad);
         HIP_TRY(h, hipMemcpy(rc.data(), h->d_rcache, rc.size() * 8, hipMemcpyDeviceToHost));
+        if (h->shards > 1) {  // a sharded handle keeps only its own shard exact: the other arcs from the potentials
+            std::vector<int64_t> pi(im.n_nodes);
+            HIP_TRY(h, hipMemcpy(pi.data(), h->d_pi, pi.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<int8_t> mine(im.m, 0);
+            for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+                int64_t lo, hi;
+                mcf_bucket_slice(im.bucket_off, x, h->shard, h->shards, 0, 1, &lo, &hi);
+                for (int64_t e2 = lo; e2 < hi; ++e2) mine[e2] = 1;
+            }
+            for (int64_t i = 0; i < im.m; ++i) if (!mine[i]) rc[i] = im.cost64[i] + pi[im.tail[i]] - pi[im.head[i]];
+            if (resident) *resident = 2;  // own shard resident
+        }
         for (int64_t i = 0; i < im.m; ++i) rc_out[im.orig[i]] = rc[i];
     } else {
         std::vector<int64_t> pi(im.n_nodes);

@@ -330,17 +330,32 @@ inline std::string mcf_build_image(int32_t n, int64_t m, const int32_t* tail, co
 // rc[e] = cost + pi[tail] - pi[head] (simplex.py:508-512), kept exact for every arc from here on:
 // a basis swap shifts the potentials of the re-hung subtree T2 by sigma, so exactly the arcs
 // with one end point in T2 change, by +sigma (tail inside) or -sigma (head inside).
-inline void mcf_build_rcache(McfHostImage& im) {
+// `shard` of `shards` > 1: the adjacency lists only the arcs of that rank's shard (its 1/shards share of every head
+// bucket, mcf_bucket_slice), so the rank's patch pass does 1/shards of the work and keeps exactly the reduced costs
+// it sweeps; McfView::rc_partial tells the pivot code not to trust the others.
+inline void mcf_build_rcache(McfHostImage& im, int64_t shard = 0, int64_t shards = 1) {
     const int64_t m = im.m;
     const int32_t n = im.n;
     im.rcache.assign(im.m_pad, 0);
     for (int64_t e = 0; e < m; ++e) im.rcache[e] = (int64_t)im.cost[e] + im.pi[im.tail[e]] - im.pi[im.head[e]];
+    std::vector<int8_t> mine;
+    if (shards > 1) {
+        mine.assign(m, 0);
+        for (int x = 0; x < MCF_NUM_BUCKETS; ++x) {
+            int64_t lo, hi;
+            mcf_bucket_slice(im.bucket_off, x, shard, shards, 0, 1, &lo, &hi);
+            for (int64_t e = lo; e < hi; ++e) mine[e] = 1;
+        }
+    }
+    auto own = [&](int64_t e) { return shards <= 1 || mine[e]; };
     im.adj_off.assign((size_t)n + 1, 0);
-    for (int64_t e = 0; e < m; ++e) { im.adj_off[im.tail[e] + 1]++; im.adj_off[im.head[e] + 1]++; }
+    int64_t total = 0;
+    for (int64_t e = 0; e < m; ++e) if (own(e)) { im.adj_off[im.tail[e] + 1]++; im.adj_off[im.head[e] + 1]++; total += 2; }
     for (int32_t v = 0; v < n; ++v) im.adj_off[v + 1] += im.adj_off[v];
-    im.adj.assign((size_t)(2 * m), 0);
+    im.adj.assign((size_t)total, 0);
     std::vector<int64_t> fill(im.adj_off.begin(), im.adj_off.end() - 1);
     for (int64_t e = 0; e < m; ++e) {
+        if (!own(e)) continue;
         const int64_t t = im.tail[e], h = im.head[e];
         im.adj[fill[t]++] = (h << 32) | (e << 1) | 1;
         im.adj[fill[h]++] = (t << 32) | (e << 1);

@@ -12,8 +12,10 @@ no factorisation.
 from __future__ import annotations
 
 import math
-from collections.abc import Callable, Iterable, Sequence
+from collections.abc import Callable, Iterable, Mapping, Sequence
 from dataclasses import dataclass, field
+
+import numpy as np
 
 from .exceptions import InvalidProblemError
 
@@ -87,6 +89,174 @@ class NetworkProblem:
                     f"Undirected edges do not support custom lower bounds.")
             out.append(Arc(tail=arc.tail, head=arc.head, capacity=cap, cost=arc.cost, lower=-cap))
         return tuple(out)
+
+
+class SoAProblem:
+    """A DIRECTED minimum-cost flow instance in flat integer arrays -- what the native DIMACS reader returns and the
+    engine consumes -- behind the ``NetworkProblem`` surface (``directed``, ``tolerance``, ``nodes``, ``arcs``,
+    ``validate``, ``undirected_expansion``).  Node ids are the DIMACS strings "1" .. "n" (node index + 1).
+
+    Purpose: the reference's loader builds one ``Node`` / ``Arc`` dataclass per element
+    (benchmarks/parsers/dimacs.py:77-102 -> data.py:532-567), which is what makes a 16 M-arc file unloadable there.
+    ``solve_min_cost_flow`` / ``NetworkSimplex`` accept this object directly and never touch ``nodes`` / ``arcs``;
+    those two are materialised lazily for code that really wants the object model (O(n + m) Python objects)."""
+
+    directed = True
+
+    def __init__(self, n: int, tail, head, cost, capacity, supply, lower=None, tolerance: float = 1e-6,
+                 name: str = "instance"):
+        self.n = int(n)
+        self.tail = np.ascontiguousarray(tail, dtype=np.int32)
+        self.head = np.ascontiguousarray(head, dtype=np.int32)
+        self.cost = np.ascontiguousarray(cost, dtype=np.int64)
+        self.capacity = np.ascontiguousarray(capacity, dtype=np.int64)        # -1 = unlimited
+        self.supply = np.ascontiguousarray(supply, dtype=np.int64)
+        m = self.tail.shape[0]
+        self.lower = np.zeros(m, dtype=np.int64) if lower is None else np.ascontiguousarray(lower, dtype=np.int64)
+        self.tolerance = float(tolerance)
+        self.name = name
+        self._nodes = None
+        self._arcs = None
+        self.validate()
+
+    @property
+    def m(self) -> int:
+        return int(self.tail.shape[0])
+
+    @property
+    def cap(self) -> np.ndarray:   # the generators' name for the same array
+        return self.capacity
+
+    def validate(self) -> None:
+        """The checks of NetworkProblem.validate and Arc.__post_init__ (data.py:78-88, 141-160), vectorised."""
+        m = self.m
+        if not (self.head.shape[0] == self.cost.shape[0] == self.capacity.shape[0] == self.lower.shape[0] == m):
+            raise InvalidProblemError("Arc arrays differ in length.")
+        if self.supply.shape[0] != self.n:
+            raise InvalidProblemError("Supply array must have one entry per node.")
+        total = int(self.supply.sum())
+        if abs(total) > self.tolerance:
+            raise InvalidProblemError(
+                f"Problem is unbalanced: total supply {float(total):.6f} exceeds tolerance {self.tolerance}. "
+                f"The sum of all node supplies must equal zero.")
+        if m == 0:
+            return
+        bad = (self.tail < 0) | (self.tail >= self.n) | (self.head < 0) | (self.head >= self.n)
+        if bad.any():
+            i = int(np.nonzero(bad)[0][0])
+            raise InvalidProblemError(
+                f"Arc tail '{int(self.tail[i]) + 1}' or head '{int(self.head[i]) + 1}' not found in node set. "
+                f"All arc endpoints must reference existing nodes.")
+        loops = self.tail == self.head
+        if loops.any():
+            i = int(np.nonzero(loops)[0][0])
+            raise InvalidProblemError(
+                f"Self-loop detected on node '{int(self.tail[i]) + 1}'. Self-loops are not supported in network simplex.")
+        short = (self.capacity >= 0) & (self.capacity < self.lower)
+        if short.any():
+            i = int(np.nonzero(short)[0][0])
+            raise InvalidProblemError(
+                f"Arc {int(self.tail[i]) + 1} -> {int(self.head[i]) + 1} has capacity ({float(self.capacity[i])}) less than "
+                f"lower bound ({float(self.lower[i])}). Capacity must be >= lower bound.")
+
+    # ---- the object model, on demand
+    @property
+    def nodes(self) -> dict[str, Node]:
+        if self._nodes is None:
+            self._nodes = {str(i + 1): Node(id=str(i + 1), supply=float(s)) for i, s in enumerate(self.supply.tolist())}
+        return self._nodes
+
+    @property
+    def arcs(self) -> list[Arc]:
+        if self._arcs is None:
+            self._arcs = [Arc(tail=str(t + 1), head=str(h + 1), capacity=None if cp < 0 else float(cp), cost=float(c),
+                              lower=float(lo))
+                          for t, h, cp, c, lo in zip(self.tail.tolist(), self.head.tolist(), self.capacity.tolist(),
+                                                     self.cost.tolist(), self.lower.tolist())]
+        return self._arcs
+
+    def undirected_expansion(self) -> Sequence[Arc]:
+        return tuple(self.arcs)
+
+    def to_network_problem(self) -> NetworkProblem:
+        return NetworkProblem(directed=True, nodes=dict(self.nodes), arcs=list(self.arcs), tolerance=self.tolerance)
+
+
+class LazyFlows(Mapping):
+    """``FlowResult.flows`` of an SoA solve: the reference's dict view -- parallel arcs summed per ``(tail, head)`` key,
+    ``|f| <= tolerance`` dropped, ``round(f, 12)`` (simplex.py:1703-1721) -- built from the flat flow array on first
+    use.  ``array`` is the per-arc flow in the problem's arc order."""
+
+    def __init__(self, tail: np.ndarray, head: np.ndarray, flow: np.ndarray, tolerance: float):
+        self._tail, self._head, self.array, self._tol = tail, head, flow, tolerance
+        self._dict: dict[tuple[str, str], float] | None = None
+
+    def _build(self) -> dict[tuple[str, str], float]:
+        if self._dict is None:
+            nz = np.nonzero(self.array)[0]
+            out: dict[tuple[str, str], float] = {}
+            for t, h, f in zip((self._tail[nz] + 1).tolist(), (self._head[nz] + 1).tolist(), self.array[nz].tolist()):
+                key = (str(t), str(h))
+                out[key] = out.get(key, 0.0) + float(f)
+            self._dict = {k: float(round(v, 12)) for k, v in out.items() if abs(v) > self._tol}
+        return self._dict
+
+    def __getitem__(self, key):
+        return self._build()[key]
+
+    def __iter__(self):
+        return iter(self._build())
+
+    def __len__(self) -> int:
+        return len(self._build())
+
+    def __repr__(self) -> str:
+        return f"LazyFlows({int(np.count_nonzero(self.array))} non-zero arc flows)"
+
+
+class LazyDuals(Mapping):
+    """``FlowResult.duals`` of an SoA solve: ``{"i": round(pi, 12)}`` built on first use; ``array`` holds them flat."""
+
+    def __init__(self, values: np.ndarray):
+        self.array = values
+        self._dict: dict[str, float] | None = None
+
+    def _build(self) -> dict[str, float]:
+        if self._dict is None:
+            self._dict = {str(i + 1): float(round(v, 12)) for i, v in enumerate(self.array.tolist())}
+        return self._dict
+
+    def __getitem__(self, key):
+        return self._build()[key]
+
+    def __iter__(self):
+        return iter(self._build())
+
+    def __len__(self) -> int:
+        return int(self.array.shape[0])
+
+
+class ArrayBasis:
+    """Warm-start basis of an SoA solve: what ``Basis`` holds (data.py:226-266), as per-arc arrays in the problem's
+    arc order.  ``tree_arcs`` / ``arc_flows`` give the reference's set / dict view on demand."""
+
+    def __init__(self, tail: np.ndarray, head: np.ndarray, in_tree: np.ndarray, at_upper: np.ndarray, flow: np.ndarray):
+        self._tail, self._head = tail, head
+        self.in_tree = np.ascontiguousarray(in_tree, dtype=np.int8)
+        self.at_upper = np.ascontiguousarray(at_upper, dtype=np.int8)
+        self.flow = flow
+
+    def _keys(self, idx):
+        return [(str(t), str(h)) for t, h in zip((self._tail[idx] + 1).tolist(), (self._head[idx] + 1).tolist())]
+
+    @property
+    def tree_arcs(self) -> set[tuple[str, str]]:
+        return set(self._keys(np.nonzero(self.in_tree)[0]))
+
+    @property
+    def arc_flows(self) -> dict[tuple[str, str], float]:
+        idx = np.nonzero(self.in_tree | self.at_upper)[0]
+        return dict(zip(self._keys(idx), (float(f) for f in self.flow[idx].tolist())))
 
 
 @dataclass

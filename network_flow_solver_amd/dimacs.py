@@ -17,85 +17,107 @@ from pathlib import Path
 
 import numpy as np
 
-from .data import NetworkProblem, build_problem
+from .data import NetworkProblem, SoAProblem, build_problem
 from .exceptions import InvalidProblemError
-from .generators import ArcSoA
+
+
+# Messages are part of the interface (callers and the reference's tests match on them); the reader below is a small
+# table-driven state machine: one handler per record kind, the record's shape checked against a spec before the
+# handler sees it.
+_MSG = {
+    "p_twice": "Multiple problem descriptor lines found. Only one 'p min' line is allowed.",
+    "p_shape": "Invalid problem descriptor format. Expected 'p min <nodes> <arcs>', got: {line}",
+    "p_kind": "Only 'min' (minimum cost flow) problems supported. Got: {kind}",
+    "p_nodes": "Number of nodes must be positive, got {n}",
+    "p_arcs": "Number of arcs cannot be negative, got {m}",
+    "n_early": "Node descriptor before problem descriptor. The 'p min' line must come first.",
+    "n_shape": "Invalid node descriptor format. Expected 'n <node_id> <supply>', got: {line}",
+    "a_early": "Arc descriptor before problem descriptor. The 'p min' line must come first.",
+    "a_shape": "Invalid arc descriptor format. Expected 'a <tail> <head> <lower> <capacity> <cost>' or "
+               "'a <tail> <head> <capacity> <cost>', got: {line}",
+    "unknown": "Unknown line type '{kind}'. Expected 'c' (comment), 'p' (problem), 'n' (node), or 'a' (arc).",
+}
+
+
+class _DimacsReader:
+    """Collects the records of a 'p min' file.  ``feed(line_no, text)`` per line, then ``finish()``."""
+
+    def __init__(self):
+        self.n_nodes: int | None = None
+        self.n_arcs: int | None = None
+        self.supplies: dict[str, float] = {}
+        self.arcs: list[tuple[str, str, float, float | None, float]] = []
+        self._handlers = {"p": self._problem, "n": self._node, "a": self._arc}
+
+    @staticmethod
+    def _fail(line_no: int, key: str, **kw):
+        raise InvalidProblemError(f"Line {line_no}: " + _MSG[key].format(**kw))
+
+    def feed(self, line_no: int, raw: str) -> None:
+        line = raw.strip()
+        if not line or line[0] == "c":
+            return
+        fields = line.split()
+        handler = self._handlers.get(fields[0])
+        if handler is None:
+            self._fail(line_no, "unknown", kind=fields[0])
+        try:
+            handler(line_no, line, fields[1:])
+        except (ValueError, IndexError) as exc:
+            raise InvalidProblemError(f"Line {line_no}: Failed to parse line: {line}. Error: {exc}") from exc
+
+    def _problem(self, line_no: int, line: str, f: list[str]) -> None:
+        if self.n_nodes is not None:
+            self._fail(line_no, "p_twice")
+        if len(f) != 3:
+            self._fail(line_no, "p_shape", line=line)
+        if f[0] != "min":
+            self._fail(line_no, "p_kind", kind=f[0])
+        n, m = int(f[1]), int(f[2])
+        self.n_nodes, self.n_arcs = n, m            # (recorded first: a bad count still counts as "seen")
+        if n <= 0:
+            self._fail(line_no, "p_nodes", n=n)
+        if m < 0:
+            self._fail(line_no, "p_arcs", m=m)
+
+    def _node(self, line_no: int, line: str, f: list[str]) -> None:
+        if self.n_nodes is None:
+            self._fail(line_no, "n_early")
+        if len(f) != 2:
+            self._fail(line_no, "n_shape", line=line)
+        self.supplies[f[0]] = float(f[1])
+
+    def _arc(self, line_no: int, line: str, f: list[str]) -> None:
+        if self.n_nodes is None:
+            self._fail(line_no, "a_early")
+        if len(f) not in (4, 5):
+            self._fail(line_no, "a_shape", line=line)
+        lower = float(f[2]) if len(f) == 5 else 0.0          # 4 fields: no lower bound (dimacs.py:194-207)
+        cap_text, cost = f[-2], float(f[-1])
+        unlimited = cap_text == "-1" or cap_text.lower() == "inf" or float(cap_text) >= 1e15   # dimacs.py:216-221
+        self.arcs.append((f[0], f[1], lower, None if unlimited else float(cap_text), cost))
+
+    def finish(self):
+        if self.n_nodes is None:
+            raise InvalidProblemError(
+                "No problem descriptor found. DIMACS file must contain a 'p min <nodes> <arcs>' line.")
+        if self.n_arcs != len(self.arcs):
+            raise InvalidProblemError(
+                f"Arc count mismatch: problem descriptor specifies {self.n_arcs} arcs, but {len(self.arcs)} arc "
+                f"descriptors found.")
+        known = {str(i) for i in range(1, self.n_nodes + 1)}
+        stray = {end for t, h, *_ in self.arcs for end in (t, h)} - known
+        if stray:
+            raise InvalidProblemError(
+                f"Arc references node IDs outside the expected range [1, {self.n_nodes}]: {sorted(stray)}")
+        return self.n_nodes, self.supplies, self.arcs
 
 
 def _scan(lines):
-    """Yield validated (kind, fields, line_no) records; shared by both front ends."""
-    seen_p = False
-    n_nodes = n_arcs = None
-    supplies: dict[str, float] = {}
-    arcs: list[tuple[str, str, float, float | None, float]] = []
+    reader = _DimacsReader()
     for line_no, raw in enumerate(lines, start=1):
-        line = raw.strip()
-        if not line or line.startswith("c"):
-            continue
-        tok = line.split()
-        kind = tok[0]
-        try:
-            if kind == "p":
-                if seen_p:
-                    raise InvalidProblemError(
-                        f"Line {line_no}: Multiple problem descriptor lines found. Only one 'p min' line is allowed.")
-                if len(tok) != 4:
-                    raise InvalidProblemError(
-                        f"Line {line_no}: Invalid problem descriptor format. Expected 'p min <nodes> <arcs>', got: {line}")
-                if tok[1] != "min":
-                    raise InvalidProblemError(
-                        f"Line {line_no}: Only 'min' (minimum cost flow) problems supported. Got: {tok[1]}")
-                n_nodes, n_arcs = int(tok[2]), int(tok[3])
-                seen_p = True
-                if n_nodes <= 0:
-                    raise InvalidProblemError(f"Line {line_no}: Number of nodes must be positive, got {n_nodes}")
-                if n_arcs < 0:
-                    raise InvalidProblemError(f"Line {line_no}: Number of arcs cannot be negative, got {n_arcs}")
-            elif kind == "n":
-                if not seen_p:
-                    raise InvalidProblemError(
-                        f"Line {line_no}: Node descriptor before problem descriptor. The 'p min' line must come first.")
-                if len(tok) != 3:
-                    raise InvalidProblemError(
-                        f"Line {line_no}: Invalid node descriptor format. Expected 'n <node_id> <supply>', got: {line}")
-                supplies[tok[1]] = float(tok[2])
-            elif kind == "a":
-                if not seen_p:
-                    raise InvalidProblemError(
-                        f"Line {line_no}: Arc descriptor before problem descriptor. The 'p min' line must come first.")
-                if len(tok) == 6:
-                    tail, head, lower, cap_s, cost = tok[1], tok[2], float(tok[3]), tok[4], float(tok[5])
-                elif len(tok) == 5:
-                    tail, head, lower, cap_s, cost = tok[1], tok[2], 0.0, tok[3], float(tok[4])
-                else:
-                    raise InvalidProblemError(
-                        f"Line {line_no}: Invalid arc descriptor format. Expected 'a <tail> <head> <lower> "
-                        f"<capacity> <cost>' or 'a <tail> <head> <capacity> <cost>', got: {line}")
-                if cap_s == "-1" or cap_s.lower() == "inf":
-                    cap = None
-                else:
-                    cap_v = float(cap_s)
-                    cap = None if cap_v >= 1e15 else cap_v
-                arcs.append((tail, head, lower, cap, cost))
-            else:
-                raise InvalidProblemError(
-                    f"Line {line_no}: Unknown line type '{kind}'. Expected 'c' (comment), 'p' (problem), "
-                    f"'n' (node), or 'a' (arc).")
-        except (ValueError, IndexError) as exc:
-            raise InvalidProblemError(f"Line {line_no}: Failed to parse line: {line}. Error: {exc}") from exc
-    if not seen_p:
-        raise InvalidProblemError(
-            "No problem descriptor found. DIMACS file must contain a 'p min <nodes> <arcs>' line.")
-    if n_arcs != len(arcs):
-        raise InvalidProblemError(
-            f"Arc count mismatch: problem descriptor specifies {n_arcs} arcs, but {len(arcs)} arc descriptors found.")
-    valid = {str(i) for i in range(1, n_nodes + 1)}
-    stray = {t for t, *_ in arcs} | {a[1] for a in arcs}
-    stray -= valid
-    if stray:
-        raise InvalidProblemError(
-            f"Arc references node IDs outside the expected range [1, {n_nodes}]: {sorted(stray)}")
-    return n_nodes, supplies, arcs
+        reader.feed(line_no, raw)
+    return reader.finish()
 
 
 def _parse_lines(lines) -> NetworkProblem:
@@ -110,27 +132,53 @@ def parse_dimacs_string(dimacs_content: str) -> NetworkProblem:
     return _parse_lines(dimacs_content.strip().split("\n"))
 
 
-def parse_dimacs_file(file_path: str | Path) -> NetworkProblem:
-    """dimacs.py:77-102."""
+NATIVE_MIN_ARCS = 100_000   # parse_dimacs_file(native=None): files announcing at least this many arcs take the flat path
+
+
+def _announced_arcs(path: Path) -> int:
+    """Arc count of the 'p min <nodes> <arcs>' line (0 when there is none: the object parser then reports it)."""
+    with path.open("r", encoding="utf-8", errors="replace") as fh:
+        for raw in fh:
+            tok = raw.split()
+            if tok and tok[0] == "p":
+                try:
+                    return int(tok[3])
+                except (IndexError, ValueError):
+                    return 0
+    return 0
+
+
+def parse_dimacs_file(file_path: str | Path, native: bool | None = None) -> NetworkProblem | SoAProblem:
+    """dimacs.py:77-102.  ``native`` selects the library's reader (``mcf_dimacs_scan`` / ``mcf_dimacs_load``), which
+    returns an ``SoAProblem`` -- flat integer arrays behind the NetworkProblem surface, no Python object per arc, the
+    form ``solve_min_cost_flow`` hands to the engine as is.  ``None``: native from NATIVE_MIN_ARCS announced arcs on
+    (integer data; a file with non-integral numbers falls back to the object parser), else the reference's object model."""
     path = Path(file_path)
     if not path.exists():
         raise FileNotFoundError(f"DIMACS file not found: {file_path}")
+    if native is None:
+        native = _announced_arcs(path) >= NATIVE_MIN_ARCS
+        if native:
+            try:
+                return parse_dimacs_soa(path)
+            except InvalidProblemError as exc:
+                if "integer" not in str(exc):
+                    raise
+                native = False
+    if native:
+        return parse_dimacs_soa(path)
     with path.open("r", encoding="utf-8") as fh:
         return _parse_lines([ln.rstrip("\n\r") for ln in fh])
 
 
-def parse_dimacs_soa(file_path: str | Path) -> ArcSoA:
-    """DIMACS text -> flat integer arrays (0-based ids) through the library's native reader
-    (``mcf_dimacs_scan`` / ``mcf_dimacs_load``): no per-arc Python objects, so it scales to the
-    16 M-arc instances the object model cannot hold.
-    Integer data and zero lower bounds only -- what netgen / gridgen / goto emit; anything else
-    should go through ``parse_dimacs_file``."""
+def parse_dimacs_soa(file_path: str | Path) -> SoAProblem:
+    """DIMACS text -> ``SoAProblem`` (0-based flat integer arrays, lower bounds included) through the library's native
+    reader: no per-arc Python objects, so it scales to the 16 M-arc instances the object model cannot hold
+    (SURVEY.md section 8f item 1).  Integer data only -- what netgen / gridgen / goto emit."""
     from . import engine
 
     path = Path(file_path)
     if not path.exists():
         raise FileNotFoundError(f"DIMACS file not found: {file_path}")
     n, tail, head, lower, cap, cost, supply = engine.dimacs_load(str(path))
-    if lower.any():
-        raise InvalidProblemError("parse_dimacs_soa supports zero lower bounds only; use parse_dimacs_file.")
-    return ArcSoA(n, tail, head, cost, cap, supply, name=path.name)
+    return SoAProblem(n, tail, head, cost, cap, supply, lower=lower, tolerance=1e-6, name=path.name)

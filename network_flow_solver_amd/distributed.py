@@ -74,11 +74,40 @@ class HipShardEngine:
     def set_max_pivots(self, total: int) -> None:
         self.eng.set_max_pivots(total)
 
+    # candidate-list rule: one sweep -> a LIST of candidates per rank -> one all-gather -> minor_cap + 1 pivots
+    def list_info(self) -> tuple[int, int]:
+        return self.eng.shard_info()
+
+    def new_list_buffers(self, world: int, list_len: int):
+        t = self.torch
+        return (t.full((2 * list_len,), -1, dtype=t.int64, device=self.device),
+                t.full((2 * list_len * world,), -1, dtype=t.int64, device=self.device))
+
+    def price_list(self, out) -> None:
+        self.eng.enqueue_price_list(self._stream(), out.data_ptr())
+
+    def pivots(self, cands, ncand: int, count: int) -> None:
+        self.eng.enqueue_pivots(self._stream(), cands.data_ptr(), ncand, count)
+
     def close(self) -> None:
         self.eng.close()
 
 
-def _enqueue_batch(eng, dist, world, local, gathered, batch, group, gather):
+def _enqueue_batch(eng, dist, world, local, gathered, batch, group, gather, listing=None):
+    """`batch` pivot slots.  listing = (list_len, minor_cap) selects the candidate-list protocol: one sweep, ONE
+    all-gather of the ranks' candidate lists, then minor_cap + 1 replicated pivots that re-price the gathered list --
+    the collective is amortised over minor_cap + 1 pivots ("amortisation lever")."""
+    if listing is not None:
+        list_len, minor_cap = listing
+        per = minor_cap + 1
+        for _ in range(max(1, (batch + per - 1) // per)):
+            eng.price_list(local)
+            if gather:
+                dist.all_gather_into_tensor(gathered, local, group=group)
+                eng.pivots(gathered, list_len * world, per)
+            else:
+                eng.pivots(local, list_len, per)
+        return
     for _ in range(batch):
         eng.price_local(local)
         if gather:
@@ -97,10 +126,14 @@ class PivotLoop:
     failure while capturing falls back to the eager loop."""
 
     def __init__(self, eng, dist, world: int, batch: int = 32, group=None, always_gather: bool = False,
-                 use_graph: bool = False):
+                 use_graph: bool = False, listing: bool = False):
         self.eng, self.dist, self.world, self.batch, self.group = eng, dist, world, batch, group
         self.gather = world > 1 or always_gather
-        self.local, self.gathered = eng.new_candidate_buffers(world)
+        self.listing = eng.list_info() if listing else None       # candidate-list rule: (list length per rank, minor cap)
+        if self.listing is not None:
+            self.local, self.gathered = eng.new_list_buffers(world, self.listing[0])
+        else:
+            self.local, self.gathered = eng.new_candidate_buffers(world)
         self.graph = None
         self.graph_error = None
         if use_graph and hasattr(eng, "torch"):
@@ -110,14 +143,14 @@ class PivotLoop:
         torch = self.eng.torch
         try:
             # one eager batch first: communicator set-up and lazy allocations must not be captured
-            _enqueue_batch(self.eng, self.dist, self.world, self.local, self.gathered, 1, self.group, self.gather)
+            _enqueue_batch(self.eng, self.dist, self.world, self.local, self.gathered, 1, self.group, self.gather, self.listing)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 _enqueue_batch(self.eng, self.dist, self.world, self.local, self.gathered, self.batch, self.group,
-                               self.gather)
+                               self.gather, self.listing)
             torch.cuda.current_stream().wait_stream(side)
             self.graph = g
         except Exception as exc:  # capture unsupported here: stay eager
@@ -134,15 +167,16 @@ class PivotLoop:
                 self.graph.replay()
             else:
                 _enqueue_batch(self.eng, self.dist, self.world, self.local, self.gathered, self.batch, self.group,
-                               self.gather)
+                               self.gather, self.listing)
             status, pivots = self.eng.poll()
             if status is not None:
                 return status, pivots
 
 
-def run_pivots(eng, dist, world: int, max_total_pivots: int, batch: int = 32, group=None, always_gather: bool = False):
+def run_pivots(eng, dist, world: int, max_total_pivots: int, batch: int = 32, group=None, always_gather: bool = False,
+               listing: bool = False):
     """Eager convenience wrapper (used by the gloo tests)."""
-    return PivotLoop(eng, dist, world, batch, group, always_gather).run(max_total_pivots)
+    return PivotLoop(eng, dist, world, batch, group, always_gather, listing=listing).run(max_total_pivots)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -187,7 +221,8 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         eng = HipShardEngine(inst, rule, rank, world, local_rank, full_sweeps=1)  # value counts every arc of every sweep: so price them all
         force = os.environ.get("MCF_BENCH_FORCE_DIST") == "1"  # 1-GPU rehearsal: still issue the collective
         loop = PivotLoop(eng, dist, world, batch=32, always_gather=force,
-                         use_graph=os.environ.get("MCF_DIST_GRAPH", "1") == "1")  # MCF_DIST_GRAPH=0: eager loop
+                         use_graph=os.environ.get("MCF_DIST_GRAPH", "1") == "1",  # MCF_DIST_GRAPH=0: eager loop
+                         listing=rule == 2)   # candidate list: one all-gather of the ranks' lists per minor_cap + 1 pivots
         loop.run(warmup)
         _, p0 = eng.poll()
         a0 = eng.eng.stats()["arcs_priced"]

@@ -29,7 +29,7 @@ CAP_INF = -1
 # every symbol include/mcf.h declares (tests check that the library exports each one)
 ABI_SYMBOLS = (
     "mcf_default_options", "mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis",
-    "mcf_enqueue_price", "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing",
+    "mcf_enqueue_price", "mcf_enqueue_pivot", "mcf_shard_info", "mcf_enqueue_price_list", "mcf_enqueue_pivots", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing",
     "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_get_weights", "mcf_dimacs_scan", "mcf_dimacs_load", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
 )
 
@@ -104,6 +104,9 @@ def load_library():
     lib.mcf_set_basis.argtypes = [vp, i8p, i8p]
     lib.mcf_enqueue_price.argtypes = [vp, vp, vp]
     lib.mcf_enqueue_pivot.argtypes = [vp, vp, vp, ctypes.c_int32]
+    lib.mcf_shard_info.argtypes = [vp, i32p, i32p]
+    lib.mcf_enqueue_price_list.argtypes = [vp, vp, vp]
+    lib.mcf_enqueue_pivots.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32]
     lib.mcf_poll.argtypes = [vp, vp, i32p, i64p]
     lib.mcf_set_max_pivots.argtypes = [vp, ctypes.c_int64]
     lib.mcf_time_pricing.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]
@@ -119,7 +122,7 @@ def load_library():
     lib.mcf_destroy.argtypes = [vp]
     lib.mcf_destroy.restype = None
     for name in ("mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis", "mcf_enqueue_price",
-                 "mcf_enqueue_pivot", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing", "mcf_time_copy",
+                 "mcf_enqueue_pivot", "mcf_shard_info", "mcf_enqueue_price_list", "mcf_enqueue_pivots", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing", "mcf_time_copy",
                  "mcf_get_tree", "mcf_get_reduced_costs", "mcf_get_weights", "mcf_dimacs_scan", "mcf_dimacs_load"):
         getattr(lib, name).restype = ctypes.c_int
     if lib.mcf_abi_version() != ABI_VERSION:
@@ -328,6 +331,18 @@ class McfEngine:
 
     def enqueue_pivot(self, stream: int, cands_ptr: int, ncand: int) -> None:
         self._check(self._lib.mcf_enqueue_pivot(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(cands_ptr), int(ncand)))
+
+    def shard_info(self) -> tuple[int, int]:
+        """(candidates one sweep leaves, minor pivots allowed per sweep)."""
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._check(self._lib.mcf_shard_info(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
+    def enqueue_price_list(self, stream: int, cands_out_ptr: int) -> None:
+        self._check(self._lib.mcf_enqueue_price_list(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(cands_out_ptr)))
+
+    def enqueue_pivots(self, stream: int, cands_ptr: int, ncand: int, count: int) -> None:
+        self._check(self._lib.mcf_enqueue_pivots(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(cands_ptr), int(ncand), int(count)))
 
     def poll(self, stream: int = 0):
         st, pv = ctypes.c_int32(0), ctypes.c_int64(0)

@@ -28,7 +28,8 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import engine as _engine
-from .data import Basis, FlowResult, NetworkProblem, ProgressCallback, ProgressInfo, SolverOptions
+from .data import (ArrayBasis, Basis, FlowResult, LazyDuals, LazyFlows, NetworkProblem, ProgressCallback, ProgressInfo,
+                   SoAProblem, SolverOptions)
 from .exceptions import InvalidProblemError, SolverConfigurationError, UnboundedProblemError
 
 _MAX_DECIMALS = 9
@@ -49,6 +50,68 @@ class FlatProblem:
     orig_cost: np.ndarray          # float64[m]
     flow_scale: int
     cost_scale: int
+    soa: bool = False              # built from an SoAProblem: ids / keys are virtual sequences, results stay flat
+
+
+class _IdSeq:
+    """node index -> DIMACS id string, without holding n strings."""
+
+    def __init__(self, n: int):
+        self._n = n
+
+    def __len__(self) -> int:
+        return self._n
+
+    def __getitem__(self, i: int) -> str:
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return str(i + 1)
+
+    def __iter__(self):
+        return (str(i + 1) for i in range(self._n))
+
+
+class _KeySeq:
+    """arc index -> (tail id, head id)."""
+
+    def __init__(self, tail: np.ndarray, head: np.ndarray):
+        self._tail, self._head = tail, head
+
+    def __len__(self) -> int:
+        return int(self._tail.shape[0])
+
+    def __getitem__(self, i: int) -> tuple[str, str]:
+        return (str(int(self._tail[i]) + 1), str(int(self._head[i]) + 1))
+
+
+def flatten_soa(problem: SoAProblem, tolerance: float | None = None) -> FlatProblem:
+    """SoAProblem -> the engine's arrays: the lower-bound shift of simplex.py:413-428 and the checks of :381-412,
+    vectorised; no per-arc Python object.  Arcs and nodes keep the file's order (the reference's string sort of ids,
+    :149 and :395, only decides among alternative optima and the order of pivots)."""
+    tol = problem.tolerance if tolerance is None else tolerance
+    m = problem.m
+    lower = problem.lower
+    finite = problem.capacity >= 0
+    cap = np.full(m, -1, dtype=np.int64)
+    width = problem.capacity - lower
+    if (finite & (width < 0)).any():
+        i = int(np.nonzero(finite & (width < 0))[0][0])
+        raise InvalidProblemError(
+            f"Arc capacity ({problem.capacity[i]}) is less than lower bound ({lower[i]}) for arc "
+            f"{int(problem.tail[i]) + 1} -> {int(problem.head[i]) + 1}. Capacity must be >= lower bound.")
+    cap[finite] = width[finite]
+    supply = problem.supply.copy()
+    if lower.any():
+        np.subtract.at(supply, problem.tail, lower)
+        np.add.at(supply, problem.head, lower)
+    if abs(int(supply.sum())) > tol:
+        raise InvalidProblemError(
+            f"Supplies do not balance after lower-bound adjustment: total supply {float(supply.sum()):.6f} "
+            f"exceeds tolerance {tol}.")
+    if m and (np.abs(problem.cost).max() >= 2 ** 31 or cap.max() >= 2 ** 60):
+        raise SolverConfigurationError("costs must fit int32 and capacities int60")
+    return FlatProblem(_IdSeq(problem.n), _KeySeq(problem.tail, problem.head), problem.tail, problem.head, problem.cost,
+                       cap, supply, lower.astype(np.float64), problem.cost.astype(np.float64), 1, 1, soa=True)
 
 
 def _decimal_scale(values: np.ndarray, what: str) -> int:
@@ -139,8 +202,9 @@ class NetworkSimplex:
         self.logger = logging.getLogger(__name__)
         self.problem = problem
         self.tolerance = self.options.tolerance
-        self.flat = flatten_problem(problem, self.tolerance)
-        self.node_ids = [self.ROOT_NODE] + self.flat.node_ids
+        self.flat = (flatten_soa(problem, self.tolerance) if isinstance(problem, SoAProblem)
+                     else flatten_problem(problem, self.tolerance))
+        self.node_ids = [self.ROOT_NODE] + self.flat.node_ids if not self.flat.soa else self.flat.node_ids
         self.actual_arc_count = len(self.flat.keys)
         self.degenerate_pivots = 0
         strategy = self._select_pricing_strategy()
@@ -159,12 +223,16 @@ class NetworkSimplex:
     def _select_pricing_strategy(self) -> str:
         if self.options.explicit_pricing_strategy:
             return self.options.pricing_strategy
-        nodes = self.problem.nodes
-        n = len(nodes)
         m = self.actual_arc_count
+        if self.flat.soa:
+            n = len(self.flat.node_ids)
+            non_transship = int(np.count_nonzero(self.problem.supply))
+        else:
+            nodes = self.problem.nodes
+            n = len(nodes)
+            non_transship = sum(1 for nd in nodes.values() if abs(nd.supply) > self.tolerance)
         if n == 0:
             return self.options.pricing_strategy
-        non_transship = sum(1 for nd in nodes.values() if abs(nd.supply) > self.tolerance)
         if (non_transship <= 4 and (n - non_transship) / n > 0.98 and (2 * m) / n >= 8 and 6 <= m / n <= 12):
             self.logger.info("Auto-detected grid-on-torus structure, switching to Dantzig pricing")
             return "dantzig"
@@ -178,6 +246,18 @@ class NetworkSimplex:
         non-basic arcs that sit at capacity there; the reference ignores such keys) tell the engine which
         non-basic arcs start at their upper bound."""
         f = self.flat
+        if isinstance(basis, ArrayBasis):                          # flat arrays in this problem's arc order
+            if basis.in_tree.shape[0] != len(f.keys):
+                self.logger.warning("Warm-start basis does not match the problem's arc count. Falling back to cold start.")
+                return False
+            if not basis.in_tree.any():
+                self.logger.warning("Warm-start basis is empty. Falling back to cold start.")
+                return False
+            if self.engine.set_basis(basis.in_tree, basis.at_upper):
+                self.logger.info(f"Successfully applied warm-start basis with {int(basis.in_tree.sum())} basis arcs")
+                return True
+            self.logger.warning(f"{self.engine.last_error()}. Falling back to cold start.")
+            return False
         if len(basis.tree_arcs) == 0:
             self.logger.warning("Warm-start basis is empty. Falling back to cold start.")
             return False
@@ -260,6 +340,16 @@ class NetworkSimplex:
             # simplex.py:1600-1624: no feasible flow (or none found within the budget)
             return FlowResult(objective=0.0, flows={}, status=res.status, iterations=iterations, duals={})
 
+        if f.soa:
+            # flat result: nothing per arc is boxed unless the caller looks at the dict views (simplex.py:1703-1765)
+            flow_total = res.flow + self.problem.lower                       # flow + shift, exact integers
+            objective = res.objective + int(np.dot(self.problem.lower.astype(object), self.problem.cost.astype(object))
+                                            if self.problem.lower.any() else 0)
+            at_upper = ~res.in_tree & (f.cap > 0) & (res.flow == f.cap)
+            return FlowResult(objective=float(round(float(objective), 12)),
+                              flows=LazyFlows(f.tail, f.head, flow_total, self.tolerance), status=res.status,
+                              iterations=iterations, duals=LazyDuals(res.potential.astype(np.float64)),
+                              basis=ArrayBasis(f.tail, f.head, res.in_tree, at_upper, res.flow))
         flow_value = res.flow.astype(np.float64) / f.flow_scale + f.lower   # flow + shift
         flows: dict[tuple[str, str], float] = {}
         objective = 0.0

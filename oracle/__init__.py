@@ -407,6 +407,16 @@ class EmulStepper:
         lib.emul_poll.restype = None
         lib.emul_destroy.argtypes = [ctypes.c_void_p]
         lib.emul_destroy.restype = None
+        lib.emul_set_shards.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        lib.emul_set_shards.restype = None
+        lib.emul_list_len.argtypes = [ctypes.c_void_p]
+        lib.emul_list_len.restype = ctypes.c_int32
+        lib.emul_minor_cap.argtypes = [ctypes.c_void_p]
+        lib.emul_minor_cap.restype = ctypes.c_int32
+        lib.emul_price_list.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, i64p]
+        lib.emul_price_list.restype = None
+        lib.emul_pivots.argtypes = [ctypes.c_void_p, i64p, ctypes.c_int32, ctypes.c_int32]
+        lib.emul_pivots.restype = None
         self._lib = lib
         self.m = int(len(tail))
         self._keep = [np.ascontiguousarray(tail, np.int32), np.ascontiguousarray(head, np.int32),
@@ -425,6 +435,18 @@ class EmulStepper:
 
     def pivot(self, cands: np.ndarray, ncand: int) -> None:
         self._lib.emul_pivot(self._h, _ptr(cands, ctypes.c_int64), int(ncand))
+
+    def pivots(self, cands: np.ndarray, ncand: int, count: int) -> None:
+        self._lib.emul_pivots(self._h, _ptr(cands, ctypes.c_int64), int(ncand), int(count))
+
+    def set_shards(self, shards: int) -> tuple[int, int]:
+        """Size the (virtual) pricing grid for `shards` ranks; returns (list length per rank, minor pivots per sweep)."""
+        self._lib.emul_set_shards(self._h, int(shards))
+        return int(self._lib.emul_list_len(self._h)), int(self._lib.emul_minor_cap(self._h))
+
+    def price_list(self, shard: int, shards: int, out: np.ndarray) -> None:
+        """out: int64[2 * list length] <- (key, packed arc id) per pricing workgroup of the shard."""
+        self._lib.emul_price_list(self._h, int(shard), int(shards), _ptr(out, ctypes.c_int64))
 
     def set_max_pivots(self, cap: int) -> None:
         self._lib.emul_set_max_pivots(self._h, int(cap))

@@ -253,6 +253,26 @@ void emul_price(void* h, int64_t r, int64_t G, int64_t* key_arc /*[2]*/) {
     if (e->ctx.status == MCF_RUNNING) price(*e, r, G, &key_arc[0], &key_arc[1]);
 }
 
+// Candidate-list rule over G ranks (mcf_shard_info / mcf_enqueue_price_list): the pricing grid of a sharded handle is
+// sized for m / G arcs, and a sweep leaves one candidate per (virtual) pricing workgroup.
+void emul_set_shards(void* h, int64_t G) {
+    Emul* e = static_cast<Emul*>(h);
+    e->price_blocks = mcf_price_blocks(e->im.m, G, 0);
+    e->ctx.minor_cap = mcf_minor_cap(e->price_blocks);
+}
+int32_t emul_list_len(void* h) { return static_cast<Emul*>(h)->price_blocks; }
+int32_t emul_minor_cap(void* h) { return static_cast<Emul*>(h)->ctx.minor_cap; }
+
+// out[2 * price_blocks] <- the shard's per-workgroup candidates; a no-op while minor iterations are pending
+void emul_price_list(void* h, int64_t r, int64_t G, int64_t* out) {
+    Emul* e = static_cast<Emul*>(h);
+    if (e->rule == MCF_RULE_CANDIDATE_LIST && e->ctx.minor_left > 0 && e->ctx.status == MCF_RUNNING) return;
+    if (e->ctx.status != MCF_RUNNING) return;
+    int64_t key, arc;
+    price(*e, r, G, &key, &arc);
+    for (int i = 0; i < e->price_blocks; ++i) { out[2 * i] = e->cand[i].key; out[2 * i + 1] = e->cand[i].arc; }
+}
+
 // apply the best of `ncand` (key, arc) candidates, like k_pivot + k_apply
 void emul_pivot(void* h, const int64_t* cands, int32_t ncand) {
     Emul* e = static_cast<Emul*>(h);
@@ -269,6 +289,17 @@ void emul_pivot(void* h, const int64_t* cands, int32_t ncand) {
         for (int32_t j = c.lo; j < c.hi; ++j) mcf_apply_one(e->view, c, j);
         for (int32_t j = c.prev_lo; j < c.prev_hi; ++j)
             if (j < c.lo || j >= c.hi) mcf_apply_one(e->view, c, j);
+    }
+}
+
+// `count` pivot slots on one gathered list (mcf_enqueue_pivots): the first takes the sweep's keys unless minor iterations
+// are pending, the others only re-price the list and idle once it is exhausted (k_pivot with have_sweep == 0)
+void emul_pivots(void* h, const int64_t* cands, int32_t ncand, int32_t count) {
+    Emul* e = static_cast<Emul*>(h);
+    for (int32_t i = 0; i < count; ++i) {
+        if (e->ctx.status != MCF_RUNNING) return;
+        if (i > 0 && e->ctx.minor_left <= 0) continue;
+        emul_pivot(h, cands, ncand);
     }
 }
 

@@ -215,8 +215,34 @@ def test_native_dimacs_reader_matches_object_parser(tmp_path):
     assert nfs.parse_dimacs_soa(tmp_path / "inf.min").cap.tolist() == [-1, -1]
     bad = {"nop.min": "n 1 1\n", "max.min": "p max 2 1\n", "count.min": "p min 2 2\na 1 2 0 1 1\n",
            "range.min": "p min 2 1\na 1 9 0 1 1\n", "kind.min": "p min 2 1\nx 1\n", "frac.min": "p min 2 1\na 1 2 0 1 1.5\n",
-           "lower.min": "p min 2 1\nn 1 1\nn 2 -1\na 1 2 1 5 7\n"}
+           "short.min": "p min 2 1\nn 1 1\nn 2 -1\na 1 2 6 5 7\n", "loop.min": "p min 2 1\na 1 1 0 5 7\n"}
     for name, text in bad.items():
         (tmp_path / name).write_text(text)
         with pytest.raises(nfs.InvalidProblemError):
             nfs.parse_dimacs_soa(tmp_path / name)
+    # lower bounds travel through the native reader; the shim applies the reference's shift (simplex.py:413-428)
+    (tmp_path / "lower.min").write_text("p min 3 2\nn 1 4\nn 3 -4\na 1 2 1 5 7\na 2 3 2 6 1\n")
+    low = nfs.parse_dimacs_soa(tmp_path / "lower.min")
+    assert low.lower.tolist() == [1, 2] and low.capacity.tolist() == [5, 6]
+    from network_flow_solver_amd.simplex import flatten_soa
+    f = flatten_soa(low)
+    assert f.cap.tolist() == [4, 4] and f.supply.tolist() == [3, -1, -2] and f.soa and f.keys[1] == ("2", "3")
+    # the same object behind the NetworkProblem surface
+    assert isinstance(low, nfs.SoAProblem) and low.directed and len(low.nodes) == 3 and low.arcs[1].lower == 2.0
+    obj = nfs.parse_dimacs_file(tmp_path / "lower.min")                     # small file: the object model, as in the reference
+    assert isinstance(obj, nfs.NetworkProblem) and [a.lower for a in obj.arcs] == [1.0, 2.0]
+    assert isinstance(nfs.parse_dimacs_file(tmp_path / "lower.min", native=True), nfs.SoAProblem)
+
+
+def test_lazy_result_views_behave_like_the_reference_dicts():
+    from network_flow_solver_amd.data import ArrayBasis, LazyDuals, LazyFlows
+
+    tail = np.array([0, 0, 1, 0], np.int32)
+    head = np.array([1, 1, 2, 2], np.int32)
+    flows = LazyFlows(tail, head, np.array([3, 2, 5, 0], np.int64), 1e-6)
+    assert flows == {("1", "2"): 5.0, ("2", "3"): 5.0} and len(flows) == 2 and ("1", "3") not in flows   # parallel arcs summed
+    assert dict(flows.items())[("2", "3")] == 5.0 and sorted(flows) == [("1", "2"), ("2", "3")]
+    duals = LazyDuals(np.array([0.0, -3.0, 7.5]))
+    assert duals["2"] == -3.0 and len(duals) == 3 and list(duals)[:2] == ["1", "2"]
+    b = ArrayBasis(tail, head, np.array([1, 0, 1, 0]), np.array([0, 1, 0, 0]), np.array([3, 2, 5, 0], np.int64))
+    assert b.tree_arcs == {("1", "2"), ("2", "3")} and b.arc_flows[("2", "3")] == 5.0

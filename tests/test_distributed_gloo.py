@@ -48,6 +48,20 @@ class EmulShardEngine:
     def pivot(self, cands, ncand):
         self.st.pivot(cands.numpy(), ncand)
 
+    # candidate-list rule: per-rank candidate LISTS, one collective per minor_cap + 1 pivots
+    def list_info(self):
+        return self.st.set_shards(self.world)
+
+    def new_list_buffers(self, world, list_len):
+        t = self.torch
+        return t.full((2 * list_len,), -1, dtype=t.int64), t.full((2 * list_len * world,), -1, dtype=t.int64)
+
+    def price_list(self, out):
+        self.st.price_list(self.rank, self.world, out.numpy())
+
+    def pivots(self, cands, ncand, count):
+        self.st.pivots(cands.numpy(), ncand, count)
+
     def poll(self):
         st, pivots, _, _ = self.st.poll()
         return st, pivots
@@ -56,7 +70,7 @@ class EmulShardEngine:
         self.st.set_max_pivots(total)
 
 
-def _worker(rank, world, port, rule, idx, queue):
+def _worker(rank, world, port, rule, idx, queue, listing=False):
     import sys
 
     sys.path.insert(0, str(ROOT))
@@ -70,9 +84,9 @@ def _worker(rank, world, port, rule, idx, queue):
         _, inst = load_synthetic()[idx]
         eng = EmulShardEngine(inst, rule, rank, world)
         # first a capped leg (exercises the limit / resume path), then to the end
-        status, pivots = distributed.run_pivots(eng, dist, world, 40, batch=8)
+        status, pivots = distributed.run_pivots(eng, dist, world, 40, batch=8, listing=listing)
         assert status == 2 and pivots == 40
-        status, pivots = distributed.run_pivots(eng, dist, world, 10 ** 9, batch=16)
+        status, pivots = distributed.run_pivots(eng, dist, world, 10 ** 9, batch=16, listing=listing)
         st, pv, objective, flow = eng.st.poll(want_flow=True)
         queue.put((rank, status, pivots, objective, flow.tolist()))
     finally:
@@ -111,3 +125,30 @@ def test_sharded_replicas_match_single_process(world, rule, idx):
             # candidate list: sharded, the list is the gathered per-rank bests (one entry per rank), so the
             # pivot sequence depends on the rank count; the replicas must still agree with each other
             assert pivots == results[0][2] and flow == results[0][4]
+
+
+@pytest.mark.parametrize("world,idx", [(2, 3), (3, 7)])
+def test_sharded_candidate_lists_one_collective_per_minor_round(world, idx):
+    """The amortised multi-GPU loop: every rank sweeps its shard into a LIST of candidates (one
+    per pricing workgroup), ONE all-gather moves the lists, then minor_cap + 1 replicated pivots re-price the gathered
+    list.  Replicas stay bit-identical, reach the single-process optimum, and the number of collectives per pivot is
+    ~1 / (minor_cap + 1) instead of 1."""
+    import oracle
+
+    _, inst = load_synthetic()[idx]
+    single = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2)
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 2, idx, queue, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [queue.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, status, pivots, objective, flow in results:
+        assert status == 0 and objective == single["objective"]
+        assert pivots == results[0][2] and flow == results[0][4]
+    # the gathered list has `world` times the single-process entries, so the pivot count stays in the same range
+    assert results[0][2] <= 1.5 * single["pivots"]

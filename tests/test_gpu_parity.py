@@ -268,6 +268,75 @@ def test_sharded_kernels_on_one_gpu(gpu_engine_module, rule, full_sweeps):
         assert np.array_equal(single.flow, r0.flow) and np.array_equal(ts["order"], t0["order"])
 
 
+@pytest.mark.parametrize("full_sweeps", [1, -1], ids=["full_sweeps", "incremental_sweeps"])
+def test_sharded_candidate_lists_on_one_gpu(gpu_engine_module, full_sweeps):
+    """The amortised multi-GPU protocol on real hardware without RCCL: three handles on this GPU; per round
+    mcf_enqueue_price_list on each (its shard's per-workgroup candidates), the three lists put side by side (what the
+    ONE all-gather per round does), then mcf_enqueue_pivots: minor_cap + 1 pivots that re-price the gathered list.
+    Replicas stay bit-identical; every rank's resident reduced costs stay exact on ITS shard (the rank's patch walks only
+    its own adjacency); the result is the certified optimum; collectives per pivot ~ 1 / (minor_cap + 1)."""
+    import ctypes
+
+    e = gpu_engine_module
+    inst = generators.named_instance("netgen_8_10a")
+    G = 3
+    engs = [e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2, shard=(r, G), device=0,
+                        full_sweeps=full_sweeps) for r in range(G)]
+    infos = [eng.shard_info() for eng in engs]
+    assert len(set(infos)) == 1
+    K, minor_cap = infos[0]
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    buf = ctypes.c_void_p()
+    nbytes = 16 * K * G
+    assert hip.hipMalloc(ctypes.byref(buf), 2 * nbytes) == 0 and hip.hipMemset(buf, 0xff, 2 * nbytes) == 0
+    local = [buf.value + 16 * K * r for r in range(G)]
+    gathered = buf.value + nbytes
+    rounds = 0
+    try:
+        for eng in engs:
+            eng.set_max_pivots(10 ** 9)
+        done = False
+        for _batch in range(4000):
+            for _ in range(4):
+                for r, eng in enumerate(engs):
+                    eng.enqueue_price_list(0, local[r])
+                assert hip.hipMemcpyAsync(gathered, buf.value, nbytes, 3, None) == 0
+                for eng in engs:
+                    eng.enqueue_pivots(0, gathered, K * G, minor_cap + 1)
+                rounds += 1
+            assert hip.hipDeviceSynchronize() == 0
+            polls = [eng.poll() for eng in engs]
+            assert len(set(polls)) == 1
+            if _batch == 3:                                   # mid-solve: each rank's own shard of reduced costs is exact
+                pi = engs[0].tree()["pi"]
+                truth = inst.cost + pi[inst.tail] - pi[inst.head]
+                for eng in engs:
+                    rc, resident = eng.reduced_costs()
+                    assert resident and np.array_equal(rc, truth)
+            if polls[0][0] is not None:
+                done = True
+                break
+        assert done
+        results = [(eng.result(), eng.tree()) for eng in engs]
+    finally:
+        for eng in engs:
+            eng.close()
+        hip.hipFree(buf)
+    r0, t0 = results[0]
+    assert r0.status == "optimal"
+    for r, t in results[1:]:
+        assert np.array_equal(r.flow, r0.flow) and np.array_equal(r.potential, r0.potential)
+        assert np.array_equal(t["order"], t0["order"]) and np.array_equal(t["parent"], t0["parent"])
+    single, _ = _solve(e, inst, 2, fused=False, mid_loop=-1)
+    assert single.objective == r0.objective
+    check_optimality(inst, r0.flow, r0.potential)
+    assert r0.stats["pivots"] >= 2 * rounds                  # several pivots per collective, not one
+
+
 def _chain_instance(n, skip=7):
     """A path 0 -> 1 -> ... -> n-1 with capacity 10, shortcut arcs every `skip` nodes and one expensive direct
     arc; 15 units from 0 to n-1.  The optimal tree is essentially the path: cycles thousands of arcs long (the
@@ -711,6 +780,56 @@ def test_million_node_sweep_and_partial_solve(gpu_engine_module):
         basic = t["state"] == 0
         rc = inst.cost + t["pi"][inst.tail] - t["pi"][inst.head]
         assert (rc[basic] == 0).all()                                        # tree arcs keep rc == 0
+
+
+# ------------------------------------------------------------------ DIMACS file -> native reader -> engine
+@pytest.mark.parametrize("strategy", ["dantzig", "devex", "adaptive"])
+def test_dimacs_file_to_flat_problem_to_solve(gpu_engine_module, tmp_path, strategy):
+    """write DIMACS -> parse_dimacs_file(native=True) (mcf_dimacs_scan / mcf_dimacs_load, no Python object per arc)
+    -> solve_min_cost_flow on the SoAProblem -> the reference's golden status / objective / flows: its three .min
+    fixtures, the netgen_8_08a stand-in, and a variant with lower bounds (shifted natively, simplex.py:413-428)."""
+    opts = nfs.SolverOptions(pricing_strategy=strategy, explicit_pricing_strategy=True, auto_scale=False)
+    for case in CASES:
+        if "dimacs_text" not in case:
+            continue
+        f = tmp_path / (case["name"] + ".min")
+        f.write_text(case["dimacs_text"])
+        prob = nfs.parse_dimacs_file(f, native=True)
+        assert isinstance(prob, nfs.SoAProblem)
+        res = nfs.solve_min_cost_flow(prob, opts)
+        exp = next(iter(case["expected"].values()))
+        assert res.status == exp["status"] == "optimal" and res.objective == exp["objective"]
+        if strategies_agree_on(case):
+            assert res.flows == {(t, h): fl for t, h, fl in exp["flows"]}
+        assert isinstance(res.flows.array, np.ndarray) and len(res.duals) == prob.n   # flat views stay available
+    entry, inst = load_synthetic()[3]                                # netgen_8_08a(synthetic)
+    f = tmp_path / "netgen_8_08a.min"
+    generators.write_dimacs(inst, f)
+    prob = nfs.parse_dimacs_file(f, native=True)
+    res = nfs.solve_min_cost_flow(prob, opts)
+    exp = next(iter(entry["expected"].values()))
+    assert res.status == "optimal" and res.objective == exp["objective"]
+    assert np.array_equal(np.asarray(res.flows.array), np.asarray(res.flows.array, dtype=np.int64))
+    rc = check_optimality(inst, res.flows.array, res.duals.array.astype(np.int64))
+    if optimum_is_unique(inst, res.flows.array, res.basis.in_tree.astype(bool), rc):
+        assert {(int(t) - 1, int(h) - 1): v for (t, h), v in res.flows.items()} == golden_flows(exp)
+    # warm start from the flat basis: no pivots left to make
+    again = nfs.solve_min_cost_flow(prob, opts, warm_start_basis=res.basis)
+    assert again.objective == res.objective and again.iterations <= 2
+    # lower bounds: the same instance with lower = 1 on every third capacitated arc of width >= 2 has the optimum of the
+    # object-model path (which applies the reference's shift in flatten_problem)
+    lower = np.where((np.arange(inst.m) % 3 == 0) & (inst.cap >= 2), 1, 0).astype(np.int64)
+    low = nfs.SoAProblem(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, lower=lower)
+    a = nfs.solve_min_cost_flow(low, opts)
+    b = nfs.solve_min_cost_flow(low.to_network_problem(), opts)
+    assert a.status == b.status and a.objective == b.objective
+    if a.status == "optimal":
+        assert (a.flows.array >= lower).all()
+
+
+def strategies_agree_on(case) -> bool:
+    from conftest import strategies_agree
+    return strategies_agree(case)
 
 
 # ------------------------------------------------------------------ BASELINE.json sizes: solved to optimality
