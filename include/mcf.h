@@ -92,7 +92,11 @@ typedef struct mcf_options {
                                 reference; off for a caller-given block size), 1 = on, -1 = off */
     int32_t devex_stay;      /* Devex block advance: 0 = cyclic (next block after every pivot), 1 = stay on a block until it holds
                                 no eligible arc (the reference's loop, simplex_pricing.py:325-355; needs the tuner to converge) */
-    int32_t reserved[4];     /* must be 0 */
+    int32_t forward_first;   /* 1 = Dantzig / candidate-list keys rank every forward candidate above every backward one: the
+                                reference's min-cost entering rule for assignment problems (specialized_pivots.py:191-223) followed
+                                by its general pricing for what is left (simplex.py:1061-1064).  The row-scan rule it uses for
+                                transportation problems (specialized_pivots.py:69-117) IS MCF_RULE_DANTZIG_FULL. */
+    int32_t reserved[3];     /* must be 0 */
 } mcf_options;
 
 typedef struct mcf_stats {

@@ -256,6 +256,9 @@ struct McfView {
     McfSeg* seg;            // [2*n_nodes + 2] scratch
     McfCtx* ctx;
     // ---- resident reduced costs (large instances; nullptr = price by gathering potentials)
+    int32_t fwd_first;      // 1: forward candidates outrank backward ones in the Dantzig key (the reference's min-cost rule for
+                            // assignment problems looks at forward arcs only and leaves the rest to the pricing strategy,
+                            // specialized_pivots.py:191-223 + simplex.py:1061-1064)
     int32_t rc_partial;     // 1: a sharded handle keeps rcache exact for ITS OWN shard only (the patch walks a per-rank
                             // adjacency: 1/G of the work); single arcs outside the sweep are then priced from the potentials
     int64_t* rcache;        // [m_pad] rc of every arc under the current potentials, engine order
@@ -285,6 +288,13 @@ struct McfDirty {
     int32_t pad[3];
     int32_t flag[MCF_MAX_PRICE_BLOCKS];  // != 0: the workgroup has to sweep its block again
 };
+
+// Dantzig key of an eligible arc: its violation; with fwd_first a forward arc (state > 0) carries bit 61 on top, so every
+// forward candidate beats every backward one and the violation still orders each group (violations stay below 2^46).
+#define MCF_FWD_BIT ((int64_t)1 << 61)
+MCF_HD int64_t mcf_dantzig_key(int32_t fwd_first, int64_t viol, int32_t state) {
+    return (fwd_first && state > 0) ? (viol | MCF_FWD_BIT) : viol;
+}
 
 MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc) {
     return key > bkey || (key == bkey && key > 0 && arc < barc);
@@ -418,7 +428,7 @@ MCF_HD int64_t mcf_minor_key(const McfView& v, int64_t packed_arc) {
     if (s == 0) return 0;
     const int64_t rc = (v.rcache && !v.rc_partial) ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
     const int64_t viol = -s * rc;
-    return viol > 0 ? viol : 0;
+    return viol > 0 ? mcf_dantzig_key(v.fwd_first, viol, (int32_t)s) : 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shar
                     const int64_t rc = (int64_t)cs[k] + pt[u][k] - ph[u][k];
                     const int64_t viol = -(int64_t)s * rc;
                     if (viol <= 0) continue;
-                    int64_t kk = viol;
+                    int64_t kk = mcf_dantzig_key(v.fwd_first, viol, s);
                     if (RULE == MCF_RULE_DEVEX_BLOCK) {
                         const double merit = ((double)viol * (double)viol) / (double)ws[k];
                         kk = __double_as_longlong(merit);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
                     if (s == 0 || i < lo || i >= hi) continue;
                     const int64_t viol = -(int64_t)s * rcs[k];
                     if (viol <= 0) continue;
-                    int64_t kk = viol;
+                    int64_t kk = mcf_dantzig_key(v.fwd_first, viol, s);
                     if (RULE == MCF_RULE_DEVEX_BLOCK) {
                         const double merit = ((double)viol * (double)viol) / (double)ws[k];
                         kk = __double_as_longlong(merit);
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
                 if (i < hi && state[i]) {
                     const int64_t viol = -(int64_t)state[i] * rcache[i];
                     if (viol > 0) {
-                        key = viol;
+                        key = mcf_dantzig_key(v.fwd_first, viol, (int32_t)state[i]);
                         if (rule == MCF_RULE_DEVEX_BLOCK) key = __double_as_longlong(((double)viol * (double)viol) / (double)v.weight[i]);
                         best_i = i;
                         best_s = state[i];
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
                     if (!sts[u]) continue;
                     const int64_t viol = -(int64_t)sts[u] * rcs[u];
                     if (viol <= 0) continue;
-                    int64_t kk = viol;
+                    int64_t kk = mcf_dantzig_key(v.fwd_first, viol, sts[u]);
                     if (rule == MCF_RULE_DEVEX_BLOCK) {
                         const double merit = ((double)viol * (double)viol) / (double)wts[u];
                         kk = __double_as_longlong(merit);
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
                 if (!v.state[i]) continue;
                 const int64_t viol = mcf_violation(v, i);
                 if (viol <= 0) continue;
-                int64_t kk = viol;
+                int64_t kk = mcf_dantzig_key(v.fwd_first, viol, (int32_t)v.state[i]);
                 if (rule == MCF_RULE_DEVEX_BLOCK) {
                     const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
                     kk = __double_as_longlong(merit);
@@ -1393,6 +1393,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     for (int x = 0; x <= MCF_NUM_BUCKETS; ++x) v.bucket_off[x] = im.bucket_off[x];
     v.weight = opt.rule == MCF_RULE_DEVEX_BLOCK ? h->d_weight : nullptr;
     v.dx = nullptr;  // (allocated and filled by upload_image for the Devex rule)
+    v.fwd_first = opt.forward_first ? 1 : 0;
     v.arcw = h->d_arcw; v.pi = h->d_pi; v.node = h->d_node;
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
     v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
@@ -1722,7 +1723,7 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const bool found = h->h_one->key > 0 && h->h_one->arc >= 0;
     *arc = found ? ((h->h_one->arc >> 32) & (MCF_DIR_FLAG - 1)) : -1;  // caller's arc index (Devex ids carry the direction in bit 30)
-    if (key) *key = found ? h->h_one->key : 0;
+    if (key) *key = found ? (rule == MCF_RULE_DEVEX_BLOCK ? h->h_one->key : (h->h_one->key & ~MCF_FWD_BIT)) : 0;
     if (dir) {
         *dir = 0;
         if (found) {

@@ -53,7 +53,8 @@ class McfOptions(ctypes.Structure):
         ("block_size", ctypes.c_int64), ("shard_rank", ctypes.c_int64), ("shard_count", ctypes.c_int64),
         ("price_blocks", ctypes.c_int32), ("no_fused", ctypes.c_int32), ("no_rcache", ctypes.c_int32),
         ("cycle_scan", ctypes.c_int32), ("mid_loop", ctypes.c_int32), ("full_sweeps", ctypes.c_int32),
-        ("devex_tuner", ctypes.c_int32), ("devex_stay", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4),
+        ("devex_tuner", ctypes.c_int32), ("devex_stay", ctypes.c_int32), ("forward_first", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 3),
     ]
 
 
@@ -156,7 +157,7 @@ class McfEngine:
                  batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
                  shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
                  resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0, full_sweeps: int = 0,
-                 devex_tuner: int = 0, devex_stay: bool = False):
+                 devex_tuner: int = 0, devex_stay: bool = False, forward_first: bool = False):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -190,6 +191,7 @@ class McfEngine:
         opt.full_sweeps = int(full_sweeps)   # 0 auto, 1 never incremental, -1 always incremental
         opt.devex_tuner = int(devex_tuner)   # 0 auto (on unless block_size is given), 1 on, -1 off
         opt.devex_stay = 1 if devex_stay else 0
+        opt.forward_first = 1 if forward_first else 0
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule

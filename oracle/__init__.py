@@ -54,7 +54,7 @@ def _load():
         lib.ref_solve.restype = ctypes.c_int
         lib.ref_solve.argtypes = [
             ctypes.c_int, ctypes.c_int64, i32p, i32p, f64p, f64p, f64p, f64p, ctypes.c_double,
-            ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, u8p,
             ctypes.POINTER(ctypes.c_int), f64p, f64p, f64p, u8p, i64p,
         ]
         lib.ref_price_dantzig.restype = ctypes.c_int64
@@ -106,8 +106,12 @@ def solve_arrays(
     block_size: int | None = None,
     max_iterations: int | None = None,
     pivot_budget: int | None = None,
+    special: int = 0,
+    left_part: np.ndarray | None = None,
 ):
     """Raw call: nodes 1..n (0 is the root), arcs in reference-internal order.
+    ``special``: SPECIAL_TYPES value of the specialised pivot strategy the reference would install
+    (specialized_pivots.py:452-527); ``left_part``: uint8[n+1] left partition for bipartite matching.
 
     Returns (status, objective, flow[m], potential[n+1], in_tree[m], stats[5], seconds).
     """
@@ -136,6 +140,7 @@ def solve_arrays(
         int(block_size) if block_size else 0,
         -1 if max_iterations is None else int(max_iterations),
         -1 if pivot_budget is None else int(pivot_budget),
+        int(special), None if left_part is None else _ptr(np.ascontiguousarray(left_part, np.uint8), ctypes.c_uint8),
         ctypes.byref(status), ctypes.byref(objective), _ptr(flow, ctypes.c_double),
         _ptr(pot, ctypes.c_double), _ptr(in_tree, ctypes.c_uint8), _ptr(stats, ctypes.c_int64),
     )
@@ -143,6 +148,67 @@ def solve_arrays(
     if rc != 0:
         raise RuntimeError(f"ref_solve failed with code {rc}")
     return status.value, objective.value, flow[:m], pot, in_tree[:m], stats, dt
+
+
+SPECIAL_TYPES = {"general": 0, "transportation": 1, "assignment": 2, "bipartite_matching": 3, "max_flow": 4,
+                 "shortest_path": 5}
+
+
+def detect_network_type(nodes: list[dict], arcs: list[dict], directed: bool, tolerance: float):
+    """specializations.py:60-288 restated on plain dicts: (type name, left partition ids or None).
+    Source / sink / transshipment split by the PROBLEM tolerance, BFS 2-colouring over the undirected arc graph
+    (components started in node order; colour 0 = left), then the reference's order of type tests."""
+    ids = [str(nd["id"]) for nd in nodes]
+    supply = {str(nd["id"]): float(nd.get("supply", 0.0)) for nd in nodes}
+    sources = {i for i in ids if supply[i] > tolerance}
+    sinks = {i for i in ids if supply[i] < -tolerance}
+    transship = len(ids) - len(sources) - len(sinks)
+    total_supply = sum(supply[i] for i in ids if supply[i] > tolerance)
+    total_demand = sum(abs(supply[i]) for i in ids if supply[i] < -tolerance)
+    balanced = abs(total_supply - total_demand) <= tolerance
+    has_lower = any(float(a.get("lower", 0.0)) > tolerance for a in arcs)
+    adj: dict[str, list[str]] = {i: [] for i in ids}
+    for a in arcs:
+        adj[str(a["tail"])].append(str(a["head"]))
+        adj[str(a["head"])].append(str(a["tail"]))
+    colour: dict[str, int] = {}
+    bipartite = bool(ids)
+    for start in ids:
+        if not bipartite:
+            break
+        if start in colour:
+            continue
+        colour[start] = 0
+        queue = [start]
+        while queue and bipartite:
+            node = queue.pop(0)
+            for nb in adj[node]:
+                if nb not in colour:
+                    colour[nb] = 1 - colour[node]
+                    queue.append(nb)
+                elif colour[nb] == colour[node]:
+                    bipartite = False
+                    break
+    left = {i for i, c in colour.items() if c == 0} if bipartite else None
+    ns, nk = len(sources), len(sinks)
+    if transship == 0 and ns > 0 and nk > 0 and bipartite and not has_lower:
+        if all(str(a["tail"]) in sources and str(a["head"]) in sinks for a in arcs):
+            if balanced and ns == nk and all(abs(supply[i] - 1.0) <= tolerance for i in sources) \
+                    and all(abs(supply[i] + 1.0) <= tolerance for i in sinks):
+                return "assignment", left
+            return "transportation", left
+    if ns == 1 and nk == 1:
+        so, si = next(iter(sources)), next(iter(sinks))
+        if abs(supply[so] - 1.0) <= tolerance and abs(supply[si] + 1.0) <= tolerance:
+            return "shortest_path", left
+    if bipartite and not has_lower:
+        if all(abs(abs(supply[i]) - 1.0) <= tolerance or abs(supply[i]) <= tolerance for i in ids):
+            return "bipartite_matching", left
+    if ns == 1 and nk == 1 and not has_lower:
+        costs = [float(a.get("cost", 0.0)) for a in arcs]
+        if all(abs(c) <= tolerance for c in costs) or all(abs(c - 1.0) <= tolerance for c in costs):
+            return "max_flow", left
+    return "general", left
 
 
 def solve_dicts(
@@ -158,10 +224,19 @@ def solve_dicts(
 
     Mirrors ``NetworkSimplex.__init__`` ordering: node ids sorted as strings
     (simplex.py:149), arcs sorted by (tail, head) strings (simplex.py:395),
-    undirected edges expanded to lower = -capacity (data.py:162-223).
+    undirected edges expanded to lower = -capacity (data.py:162-223); the network
+    type decides which specialised pivot strategy runs first (simplex.py:133-137, 259-261).
     """
     ids = sorted(str(nd["id"]) for nd in nodes)
     index = {nid: i + 1 for i, nid in enumerate(ids)}
+    if "special" not in kw:
+        kind, left = detect_network_type(nodes, arcs, directed, tolerance)
+        kw["special"] = SPECIAL_TYPES[kind]
+        if left is not None and kind == "bipartite_matching":
+            lp = np.zeros(len(ids) + 1, dtype=np.uint8)
+            for nid in left:
+                lp[index[nid]] = 1
+            kw["left_part"] = lp
     supply = np.zeros(len(ids), dtype=np.float64)
     for nd in nodes:
         supply[index[str(nd["id"])] - 1] = float(nd.get("supply", 0.0))

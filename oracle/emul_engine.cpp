@@ -27,6 +27,7 @@ struct Emul {
     McfCtx ctx;
     McfView view;
     int rule = 0;
+    int fwd_first = 0;          // bit 8 of the `rule` argument: forward candidates first (mcf_options.forward_first)
     int price_blocks = 8;
     std::vector<McfCand> cand;  // candidate-list rule: one entry per (virtual) pricing workgroup
     McfDevex dx;                // Devex: granule table + touched-weight list
@@ -70,6 +71,8 @@ void bind(Emul& e) {
     v.rec2 = e.rec2.data();
     v.seg = e.seg.data();
     v.ctx = &e.ctx;
+    v.fwd_first = e.fwd_first;
+    v.rc_partial = 0;
     v.rcache = nullptr;  // the emulation always prices by gathering potentials: an independent
     v.adj_off = nullptr; // check of the engine's resident reduced costs
     v.adj = nullptr;
@@ -103,7 +106,7 @@ int64_t price(Emul& e, int64_t r, int64_t G, int64_t* key, int64_t* arc) {
             if (!v.state[i]) continue;
             const int64_t viol = mcf_violation(v, i);
             if (viol <= 0) continue;
-            int64_t kk = viol;
+            int64_t kk = mcf_dantzig_key(v.fwd_first, viol, v.state[i]);
             if (e.rule == MCF_RULE_DEVEX_BLOCK) {
                 const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
                 std::memcpy(&kk, &merit, 8);
@@ -156,7 +159,9 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
                int32_t climb_budget /* < 0: always climb */, int64_t* scan_stats /*[2] or null*/,
                const int8_t* warm_in_tree /* null: cold start */, const int8_t* warm_at_upper, int32_t* warm_applied) {
     Emul e;
-    e.rule = rule;
+    e.rule = rule & 0xff;
+    e.fwd_first = (rule >> 8) & 1;
+    rule = e.rule;
     int err = 0;
     std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e.im, &err, bucketed != 0);
     if (err) { std::fprintf(stderr, "emul_solve: %s\n", msg.c_str()); return err; }
@@ -231,7 +236,8 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
 void* emul_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, const int64_t* cost,
                   const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int32_t bucketed) {
     Emul* e = new Emul();
-    e->rule = rule;
+    e->rule = rule & 0xff;
+    e->fwd_first = (rule >> 8) & 1;
     int err = 0;
     std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e->im, &err, bucketed != 0);
     if (err) { std::fprintf(stderr, "emul_create: %s\n", msg.c_str()); delete e; return nullptr; }

@@ -19,6 +19,7 @@
  *   Devex block search + deferred weights . simplex_pricing.py:271-292,310-372 -> select_devex()
  *   candidate list / adaptive pricing ..... simplex_pricing.py:375-639 -> select_candidate_list(), select_adaptive()
  *   block-size tuner ...................... simplex_adaptive.py:70-151 -> tuner_*()
+ *   specialised entering rules ............ specialized_pivots.py:69-424, dispatch simplex.py:1061-1064 -> select_special()
  *   pivot (ratio test, flow update, swap) . simplex.py:1176-1425 -> pivot()
  *   pivot loop ............................ simplex.py:1109-1160 -> run_iterations()
  *   two-phase driver + result extraction .. simplex.py:1446-1765 -> ref_solve()
@@ -52,6 +53,8 @@
 
 enum { ST_OPTIMAL = 0, ST_INFEASIBLE = 1, ST_ITERATION_LIMIT = 2, ST_UNBOUNDED = 3 };
 enum { PR_DANTZIG = 0, PR_DEVEX = 1, PR_CANDIDATE_LIST = 2, PR_ADAPTIVE = 3 };
+/* NetworkType values that install a specialised pivot strategy (specialized_pivots.py:452-527) */
+enum { SP_NONE = 0, SP_TRANSPORTATION = 1, SP_ASSIGNMENT = 2, SP_BIPARTITE_MATCHING = 3, SP_MAX_FLOW = 4, SP_SHORTEST_PATH = 5 };
 
 typedef struct {
     /* sizes */
@@ -97,6 +100,12 @@ typedef struct {
     int32_t *cand_tmp;
     /* adaptive (simplex_pricing.py:545-639) */
     int ad_current, ad_failed;
+    /* specialised pivot strategy (tried before the pricing strategy, simplex.py:1061-1064) */
+    int special;
+    const uint8_t *left_part;      /* bipartite matching: node is in the left partition (colour 0) */
+    int sp_source;                 /* shortest path: the unit-supply node */
+    uint8_t *sp_label;             /* shortest path: node has a finite distance label */
+    int sp_label_init;
     /* unbounded diagnostics */
     int64_t unb_arc;
 } Ref;
@@ -412,8 +421,101 @@ static int select_adaptive(Ref *s, int allow_zero, int64_t *out_arc, int *out_di
     return found;
 }
 
+
+/* ---- specialized_pivots.py: every strategy is one O(m_tot) scan of rc = cost + pi[tail] - pi[head] with its own
+ * acceptance / merit test; a strategy that finds nothing hands over to the pricing strategy.
+ *   TransportationPivotStrategy.find_entering_arc_row_scan   :69-117   most negative rc, both directions
+ *   AssignmentPivotStrategy.find_entering_arc_min_cost       :191-223  forward only, better by more than tol
+ *   BipartiteMatchingPivotStrategy.find_augmenting_path      :251-287  first arc out of an unmatched left node
+ *   MaxFlowPivotStrategy.find_entering_arc                   :312-355  merit residual * |rc|
+ *   ShortestPathPivotStrategy.find_entering_arc              :383-448  forward arcs only from labelled nodes */
+static int select_special(Ref *s, int64_t *out_arc, int *out_dir) {
+    const double tol = s->tol;
+    int have = 0;
+    s->arcs_priced += s->m_tot;
+    if (s->special == SP_TRANSPORTATION) {
+        double best_rc = 0.0;
+        for (int64_t i = 0; i < s->m_tot; ++i) {
+            if (s->in_tree[i] || s->artificial[i]) continue;
+            double rc = s->cost[i] + s->potential[s->tail[i]] - s->potential[s->head[i]];
+            if (s->fwd_res[i] > tol && rc < -tol && rc < best_rc) { best_rc = rc; *out_arc = i; *out_dir = 1; have = 1; }
+            if (s->bwd_res[i] > tol && rc > tol && -rc < best_rc) { best_rc = -rc; *out_arc = i; *out_dir = -1; have = 1; }
+        }
+        return have;
+    }
+    if (s->special == SP_ASSIGNMENT) {
+        double best_rc = 0.0;
+        for (int64_t i = 0; i < s->m_tot; ++i) {
+            if (s->in_tree[i] || s->artificial[i]) continue;
+            double rc = s->cost[i] + s->potential[s->tail[i]] - s->potential[s->head[i]];
+            if (s->fwd_res[i] > tol && rc < best_rc - tol) { best_rc = rc; *out_arc = i; *out_dir = 1; have = 1; }
+        }
+        return have;
+    }
+    if (s->special == SP_MAX_FLOW) {
+        double best = -INFINITY;
+        for (int64_t i = 0; i < s->m_tot; ++i) {
+            if (s->in_tree[i] || s->artificial[i]) continue;
+            double rc = s->cost[i] + s->potential[s->tail[i]] - s->potential[s->head[i]];
+            if (s->fwd_res[i] > tol && rc < -tol) {
+                double merit = s->fwd_res[i] * fabs(rc);
+                if (merit > best) { best = merit; *out_arc = i; *out_dir = 1; have = 1; }
+            }
+            if (s->bwd_res[i] > tol && rc > tol) {
+                double merit = s->bwd_res[i] * fabs(rc);
+                if (merit > best) { best = merit; *out_arc = i; *out_dir = -1; have = 1; }
+            }
+        }
+        return have;
+    }
+    if (s->special == SP_SHORTEST_PATH) {
+        if (!s->sp_label_init) { /* _initialize_distance_labels :450-471: BFS over the real arcs from the source */
+            s->sp_label_init = 1;
+            int qh = 0, qt = 0;
+            s->sp_label[s->sp_source] = 1; s->queue[qt++] = s->sp_source;
+            while (qh < qt) {
+                int node = s->queue[qh++];
+                for (int64_t i = 0; i < s->m_tot; ++i) {
+                    if (s->artificial[i]) continue;
+                    if (s->tail[i] == node && !s->sp_label[s->head[i]]) { s->sp_label[s->head[i]] = 1; s->queue[qt++] = s->head[i]; }
+                }
+            }
+        }
+        double best_rc = 0.0;
+        for (int64_t i = 0; i < s->m_tot; ++i) {
+            if (s->in_tree[i] || s->artificial[i]) continue;
+            double rc = s->cost[i] + s->potential[s->tail[i]] - s->potential[s->head[i]];
+            if (s->fwd_res[i] > tol && rc < -tol) {
+                /* only the finiteness of a label is ever tested: labelled = reachable from the source */
+                if (s->sp_label[s->tail[i]] && rc < best_rc - tol) {
+                    best_rc = rc; *out_arc = i; *out_dir = 1; have = 1;
+                    s->sp_label[s->head[i]] = 1;
+                }
+            }
+            if (s->bwd_res[i] > tol && rc > tol && -rc < best_rc - tol) { best_rc = -rc; *out_arc = i; *out_dir = -1; have = 1; }
+        }
+        return have;
+    }
+    if (s->special == SP_BIPARTITE_MATCHING) {
+        /* unmatched left nodes: unit supply and no basic arc carrying flow out of them.  The reference iterates Python
+         * sets of node indices; small ints iterate in increasing order, which is what is restated here. */
+        for (int v = 1; v < s->n_nodes; ++v) {
+            if (!s->left_part[v] || fabs(s->supply[v] - 1.0) > tol) continue;
+            int has_flow = 0;
+            for (int64_t i = 0; i < s->m_tot && !has_flow; ++i)
+                if (s->in_tree[i] && s->flow[i] > tol && s->tail[i] == v) has_flow = 1;
+            if (has_flow) continue;
+            for (int64_t i = 0; i < s->m_tot; ++i)
+                if (s->tail[i] == v && !s->in_tree[i] && s->fwd_res[i] > tol) { *out_arc = i; *out_dir = 1; return 1; }
+        }
+        return 0;
+    }
+    return 0;
+}
+
 /* ---- simplex.py:1058-1075 ------------------------------------------------ */
 static int find_entering_arc(Ref *s, int allow_zero, int64_t *out_arc, int *out_dir) {
+    if (s->special != SP_NONE && select_special(s, out_arc, out_dir)) return 1;
     switch (s->strategy) {
     case PR_DANTZIG: return select_dantzig_list(s, NULL, s->m_real, allow_zero, out_arc, out_dir);
     case PR_DEVEX: return select_devex(s, allow_zero, out_arc, out_dir);
@@ -533,6 +635,7 @@ static int64_t run_iterations(Ref *s, int64_t max_iterations, int allow_zero, in
 static void *xcalloc(size_t n, size_t sz) { return calloc(n ? n : 1, sz); }
 
 static void ref_free(Ref *s) {
+    free(s->sp_label);
     free(s->tail); free(s->head); free(s->cost); free(s->upper); free(s->flow); free(s->shift);
     free(s->in_tree); free(s->artificial); free(s->original_cost); free(s->perturbed_cost);
     free(s->fwd_res); free(s->bwd_res); free(s->vec_cost); free(s->supply);
@@ -560,7 +663,7 @@ static void ref_free(Ref *s) {
 int ref_solve(int n, int64_t m, const int32_t *tail, const int32_t *head, const double *cost,
               const double *cap, const double *lower, const double *supply_in, double tol,
               int strategy, int use_vectorized, int64_t block_size, int64_t max_iterations,
-              int64_t pivot_budget,
+              int64_t pivot_budget, int special, const uint8_t *left_part /* [n+1] or NULL */,
               int *status_out, double *objective_out, double *flow_out, double *potential_out,
               uint8_t *in_tree_out, int64_t *stats) {
     Ref S; memset(&S, 0, sizeof S);
@@ -569,6 +672,7 @@ int ref_solve(int n, int64_t m, const int32_t *tail, const int32_t *head, const 
     const int64_t M = m + n; /* one artificial arc per real node */
     s->n_nodes = N; s->m_real = m; s->m_tot = M; s->tol = tol;
     s->strategy = strategy; s->use_vectorized = use_vectorized; s->last_degenerate_arc = -1; s->unb_arc = -1;
+    s->special = special; s->left_part = left_part; s->sp_label = xcalloc((size_t)N, 1);
     s->tail = xcalloc((size_t)M, 4); s->head = xcalloc((size_t)M, 4);
     s->cost = xcalloc((size_t)M, 8); s->upper = xcalloc((size_t)M, 8); s->flow = xcalloc((size_t)M, 8);
     s->shift = xcalloc((size_t)M, 8); s->in_tree = xcalloc((size_t)M, 1); s->artificial = xcalloc((size_t)M, 1);
@@ -628,6 +732,25 @@ int ref_solve(int n, int64_t m, const int32_t *tail, const int32_t *head, const 
         s->weights[i] = 1.0;
         s->vec_cost[i] = s->cost[i]; /* _build_vectorized_arrays after perturbation, simplex.py:250-253 */
         set_flow(s, i, s->flow[i]);
+    }
+
+    /* select_pivot_strategy (specialized_pivots.py:452-527): some types need a source / sink or the partitions */
+    if (s->special == SP_BIPARTITE_MATCHING && !s->left_part) s->special = SP_NONE;
+    if (s->special == SP_MAX_FLOW) {
+        int src = -1, snk = -1;
+        for (int v = 1; v < N; ++v) {
+            if (s->supply[v] > tol && src < 0) src = v;
+            else if (s->supply[v] < -tol && snk < 0) snk = v;
+        }
+        if (src < 0 || snk < 0) s->special = SP_NONE;
+    }
+    if (s->special == SP_SHORTEST_PATH) {
+        int src = -1, snk = -1;
+        for (int v = 1; v < N; ++v) {
+            if (fabs(s->supply[v] - 1.0) <= tol && src < 0) src = v;
+            else if (fabs(s->supply[v] + 1.0) <= tol && snk < 0) snk = v;
+        }
+        if (src < 0 || snk < 0) s->special = SP_NONE; else s->sp_source = src;
     }
 
     if (max_iterations < 0) max_iterations = 20 * M > 100 ? 20 * M : 100; /* simplex.py:1466-1470 */

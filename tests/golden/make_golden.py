@@ -100,6 +100,29 @@ def networkx_objective(nodes, arcs, directed=True):
     return cost
 
 
+def reference_network_type(problem) -> str:
+    """What the reference's structure analysis calls this instance (specializations.py:60-288): decides which
+    specialised pivot strategy it installs (specialized_pivots.py:452-527)."""
+    from network_solver.specializations import analyze_network_structure
+
+    return analyze_network_structure(problem).network_type.value
+
+
+def add_network_types():
+    """Add the ``network_type`` field to an existing cases.json without re-solving anything:
+    python3 tests/golden/make_golden.py --network-types"""
+    cases = json.loads((HERE / "cases.json").read_text())
+    for c in cases:
+        try:
+            problem = build_problem(nodes=c["nodes"], arcs=c["arcs"], directed=c["directed"], tolerance=c["tolerance"])
+            c["network_type"] = reference_network_type(problem)
+        except Exception as exc:  # a case the reference rejects at build time keeps no type
+            c["network_type"] = None
+            print(f"  {c['name']}: {type(exc).__name__}")
+    (HERE / "cases.json").write_text(json.dumps(cases, indent=1))
+    print("done")
+
+
 def make_case(name, nodes, arcs, directed=True, tolerance=1e-6, source="", max_iterations=None):
     problem = build_problem(nodes=nodes, arcs=arcs, directed=directed, tolerance=tolerance)
     expected = {s: run_reference(problem, s, max_iterations) for s in STRATEGIES}
@@ -115,6 +138,7 @@ def make_case(name, nodes, arcs, directed=True, tolerance=1e-6, source="", max_i
         "source": source,
         "directed": directed,
         "tolerance": tolerance,
+        "network_type": reference_network_type(problem),
         "max_iterations": max_iterations,
         "nodes": nodes,
         "arcs": arcs,
@@ -382,4 +406,9 @@ def extra():
 
 
 if __name__ == "__main__":
-    extra() if "--extra" in sys.argv else main()
+    if "--network-types" in sys.argv:
+        add_network_types()
+    elif "--extra" in sys.argv:
+        extra()
+    else:
+        main()

@@ -246,3 +246,25 @@ def test_lazy_result_views_behave_like_the_reference_dicts():
     assert duals["2"] == -3.0 and len(duals) == 3 and list(duals)[:2] == ["1", "2"]
     b = ArrayBasis(tail, head, np.array([1, 0, 1, 0]), np.array([0, 1, 0, 0]), np.array([3, 2, 5, 0], np.int64))
     assert b.tree_arcs == {("1", "2"), ("2", "3")} and b.arc_flows[("2", "3")] == 5.0
+
+
+def test_structure_analysis_matches_the_reference_classification():
+    """specializations.analyze_network_structure (array based) against the class the reference itself assigned to
+    every fixture (``network_type`` in tests/golden/cases.json, recorded by make_golden.py), for the object model and
+    for the flat SoAProblem form of the DIMACS fixtures."""
+    from network_flow_solver_amd.specializations import NetworkType, analyze_network_structure
+
+    seen = set()
+    for c in CASES:
+        p = nfs.build_problem(c["nodes"], c["arcs"], c["directed"], c["tolerance"])
+        st = analyze_network_structure(p)
+        assert st.network_type.value == c["network_type"], c["name"]
+        seen.add(st.network_type)
+        if st.network_type in (NetworkType.TRANSPORTATION, NetworkType.ASSIGNMENT):
+            assert st.is_bipartite and st.partitions is not None and not st.transshipment_nodes
+    assert {NetworkType.GENERAL, NetworkType.TRANSPORTATION, NetworkType.ASSIGNMENT, NetworkType.SHORTEST_PATH,
+            NetworkType.MAX_FLOW, NetworkType.BIPARTITE_MATCHING} <= seen
+    soa = nfs.SoAProblem(4, [0, 0, 1, 1], [2, 3, 2, 3], [4, 6, 3, 5], [10, 10, 12, 15], [10, 15, -12, -13])
+    assert analyze_network_structure(soa).network_type is NetworkType.TRANSPORTATION
+    soa = nfs.SoAProblem(4, [0, 0, 1, 1], [2, 3, 2, 3], [4, 6, 3, 5], [1, 1, 1, 1], [1, 1, -1, -1])
+    assert analyze_network_structure(soa).network_type is NetworkType.ASSIGNMENT

@@ -630,6 +630,51 @@ def test_devex_pivot_counts_close_to_the_reference(gpu_engine_module):
         assert res.stats["pivots"] <= 1.2 * exp["iterations"], (entry["name"], res.stats["pivots"], exp["iterations"])
 
 
+@pytest.mark.parametrize("rule", [0, 2], ids=["dantzig", "candidate_list"])
+def test_forward_first_keys_on_every_engine_path(gpu_engine_module, rule):
+    """options.forward_first (the reference's min-cost rule for assignment problems, specialized_pivots.py:191-223:
+    forward candidates before backward ones): every engine path pivots exactly like the CPU emulation with the same
+    key, takes a different route than the plain rule, and ends at the same optimum."""
+    for idx, kws in ((3, ({}, {"fused": False}, {"fused": False, "mid_loop": -1})), (7, ({}, {"mid_loop": -1}, {"resident_rc": False}))):
+        _, inst = load_synthetic()[idx]
+        em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule | 0x100)
+        plain, _ = _solve(gpu_engine_module, inst, rule)
+        for kw in kws:
+            res, tree = _solve(gpu_engine_module, inst, rule, forward_first=True, **kw)
+            assert res.status == "optimal" and res.objective == em["objective"] == plain.objective
+            assert res.stats["pivots"] == em["pivots"] and np.array_equal(res.flow, em["flow"])
+            assert np.array_equal(tree["order"], em["order"])
+        assert em["pivots"] != plain.stats["pivots"]
+    # the key bit never leaks through the parity hook
+    with gpu_engine_module.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0, forward_first=True) as eng:
+        got = eng.price_once(0)
+        pi = eng.tree()["pi"]
+        assert got[2] == abs(int(inst.cost[got[0]] + pi[inst.tail[got[0]]] - pi[inst.head[got[0]]]))
+
+
+def test_structured_problems_take_the_specialised_rules(gpu_engine_module):
+    """Transportation and assignment fixtures through the shim: the structure analysis picks the row-scan (Dantzig)
+    and the forward-first rule whatever strategy was asked for, and the reference's optimum comes back."""
+    from network_flow_solver_amd.specializations import NetworkType
+
+    seen = set()
+    for case in CASES:
+        if case["network_type"] not in ("transportation", "assignment"):
+            continue
+        exp = case["expected"]["devex"]
+        problem = nfs.build_problem(case["nodes"], case["arcs"], case["directed"], case["tolerance"])
+        solver = nfs.NetworkSimplex(problem, nfs.SolverOptions(pricing_strategy="devex", explicit_pricing_strategy=True))
+        try:
+            assert solver.network_structure.network_type.value == case["network_type"]
+            assert solver.pricing_rule == gpu_engine_module.RULE_DANTZIG
+            res = solver.solve()
+        finally:
+            solver.engine.close()
+        assert res.status == exp["status"] and res.objective == pytest.approx(exp["objective"], abs=1e-9)
+        seen.add(solver.network_structure.network_type)
+    assert seen == {NetworkType.TRANSPORTATION, NetworkType.ASSIGNMENT}
+
+
 def test_sharded_handle_refuses_a_standalone_solve(gpu_engine_module):
     """A handle that prices 1/G of the arcs must not be solved on its own (it would call its share's optimum
     the optimum): mcf_solve returns MCF_E_STATE."""

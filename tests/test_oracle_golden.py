@@ -9,10 +9,9 @@ from conftest import CASE_IDS, CASES, golden_flows, load_synthetic
 
 STRATS = ("dantzig", "devex")
 
-# transportation / assignment / bipartite inputs make the reference take its specialised
-# pivot rules first (simplex.py:1061-1064, specialized_pivots.py) which the oracle does not
-# restate (out of scope); outcome parity still holds, pivot-count
-# parity is only claimed for GENERAL networks.
+# transportation / assignment / bipartite-matching / max-flow / shortest-path inputs make the reference try a
+# specialised pivot strategy first (simplex.py:1061-1064, specialized_pivots.py:69-527); the oracle restates the
+# structure analysis (specializations.py:60-288) and all five strategies, so pivot counts are pinned on EVERY case.
 
 
 @pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
@@ -38,15 +37,41 @@ def test_small_cases_match_reference(case, strategy):
         assert all(abs(v) <= 1e-6 for v in supplies.values())
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in (
-    "sample_problem", "dimacs_small_problem", "e2e_three_node", "simplex_five_node_70", "chain120", "chain80",
-    "undirected_chain75", "perf_chain_seed24", "small_transshipment", "lower_bounds_and_parallel",
-    "fractional_costs", "degenerate_triangle", "multi_source_multi_sink_hub")],
-    ids=lambda c: c["name"])
-def test_dantzig_pivot_counts_match_reference(case):
-    exp = case["expected"]["dantzig"]
-    res = oracle.solve_dicts(case["nodes"], case["arcs"], case["directed"], case["tolerance"], "dantzig")
+@pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
+def test_network_type_detection_matches_reference(case):
+    """The restated structure analysis classifies every fixture the way the reference does (``network_type`` was
+    recorded by tests/golden/make_golden.py from analyze_network_structure)."""
+    kind, left = oracle.detect_network_type(case["nodes"], case["arcs"], case["directed"], case["tolerance"])
+    assert kind == case["network_type"]
+    if kind == "bipartite_matching":
+        assert left
+
+
+@pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
+@pytest.mark.parametrize("strategy", STRATS)
+def test_pivot_counts_match_reference_on_every_case(case, strategy):
+    """Pivot for pivot: the iteration count of the reference itself, for the Dantzig loop and the vectorised Devex
+    path, on general networks AND on the 12 fixtures where a specialised pivot strategy runs first."""
+    exp = case["expected"][strategy]
+    if exp.get("iterations") is None:          # unbounded: the reference raises, no count recorded
+        return
+    res = oracle.solve_dicts(case["nodes"], case["arcs"], case["directed"], case["tolerance"], strategy,
+                             max_iterations=case.get("max_iterations"))
     assert res.iterations == exp["iterations"]
+
+
+def test_specialised_strategies_change_the_pivot_sequence():
+    """The specialised rules are not a no-op: switched off (special=0), at least one transportation fixture takes a
+    different number of pivots than the reference did."""
+    differs = 0
+    for case in CASES:
+        if case["network_type"] in ("transportation", "assignment"):
+            for strategy in STRATS:
+                plain = oracle.solve_dicts(case["nodes"], case["arcs"], case["directed"], case["tolerance"], strategy,
+                                           special=0)
+                assert plain.objective == pytest.approx(case["expected"][strategy]["objective"], abs=1e-9)
+                differs += plain.iterations != case["expected"][strategy]["iterations"]
+    assert differs > 0
 
 
 @pytest.mark.parametrize("entry,inst", load_synthetic(), ids=lambda x: x["name"] if isinstance(x, dict) else "")
