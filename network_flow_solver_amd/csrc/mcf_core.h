@@ -207,6 +207,8 @@ struct McfCtx {
     int32_t lo, hi;            // affected preorder range
     int32_t t2_old, t2_new, t2_size;  // old start a, new start b, |T2|
     int32_t nseg;              // entries in seg[] (sorted by dst, cover [t2_new, t2_new+t2_size))
+    int32_t nchg;              // entries in chg[]
+    int32_t pad2;
     int64_t sigma;             // potential shift of the moved subtree
     // ---- hand-over from mcf_pivot_walk (one lane) to mcf_pivot_finish (all lanes)
     int32_t stage;             // 0 = nothing to finish, 1 = bound flip, 2 = basis swap
@@ -272,7 +274,14 @@ struct McfView {
     // nullptr.  With it, "the node at position i is an ancestor of u" is i <= pos[u] < i + psz[i]: the
     // cycle can be found by a coalesced team-wide scan over preorder positions instead of a pointer
     // chase whose length is the tree depth (mcf_pivot_scan).
-    int32_t* psz[2];        // [n_nodes] each
+    int32_t* psz[2];        // [n_nodes rounded up to a coarse block + 4] each
+    // Coarse index over psz: reach[b] >= max over the positions i of block b of i + psz[i] (the end of the farthest-
+    // reaching subtree that starts in the block).  Preorder intervals are nested, so block b holds an ancestor of the
+    // node at position p exactly when b * 64 <= p < reach[b]: one pass over n / 64 words finds every block that can
+    // matter, whatever the depth of the tree, and only those are scanned position by position.  An entry may be stale
+    // on the HIGH side (a shrunken subtree not yet re-indexed): that only costs a wasted block visit.
+    int32_t* reach;         // [ceil(n_nodes / 64)] or nullptr
+    int32_t* chg;           // [n_nodes] scratch: positions whose subtree shrank in this pivot (their blocks are re-indexed by the apply pass)
     // ---- incremental pricing (nullptr = every sweep prices every block).  A pricing workgroup's best candidate
     // only changes when an arc of its block changes reduced cost or state; the passes that change arcs raise the
     // block's flag, and a full Dantzig sweep (also the candidate-list rule's) skips the blocks whose flag is down.
@@ -473,10 +482,15 @@ struct McfCycle {
 };
 
 // Accumulators of the team-wide scan (LDS on the device).
+#define MCF_REACH_SHIFT 6                  // coarse blocks of 64 preorder positions
+#define MCF_REACH_BLOCK (1 << MCF_REACH_SHIFT)
+#define MCF_SCAN_BLK_CAP 2048             // flagged coarse blocks one scan can hold (more: the plain rounds take over)
 struct McfScanAcc {
     int32_t jpos[2];       // preorder position of the deepest common ancestor met so far, -1: none yet
                            // (one slot per round parity: a round needs a single barrier)
     int32_t nhits;         // one-sided ancestors noted so far
+    int32_t nblk;          // coarse pass: blocks that may hold an ancestor of either end point
+    int32_t blk[MCF_SCAN_BLK_CAP];
     int32_t jnode;         // the join and its record (fetched while the hit pass runs)
     McfNode join;
     int64_t wr1[16], wr2[16];  // per-wave results of the ratio reduction
@@ -489,6 +503,7 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
     McfCtx* c = v.ctx;
     c->apply = 0;
     c->stage = 0;
+    c->nchg = 0;
     if (c->wreset) { c->wreset = 0; c->wlist_n = 0; }  // the previous finish pass reset the listed Devex weights
     if (c->pending_flip) {  // the previous apply pass wrote order[cur ^ 1]
         c->cur ^= 1;
@@ -643,6 +658,7 @@ MCF_HD void mcf_scan_best_merge(McfScanBest* a, int64_t r1, int32_t i1, int64_t 
 MCF_HD void mcf_scan_init(McfScanAcc* acc) {
     acc->jpos[0] = -1; acc->jpos[1] = -1;
     acc->nhits = 0;
+    acc->nblk = 0;
 }
 
 // The dense pass over the hit list: node id, record, tree arc of every one-sided ancestor (three dependent loads
@@ -683,6 +699,30 @@ MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_
 // `sp`: small buffers of `small_cap` entries each (LDS on the device; cap 0 = none); a cycle found by the
 // scan alone that fits is recorded there (cy->small = 1), which spares the decide / finish passes a
 // global round trip per look-up.  The caller has run mcf_scan_init(acc) before the barrier in front of this call.
+// Four consecutive positions i0 .. i0 + 3 with their subtree sizes: note the ancestors of the node at position pu
+// and / or pw among them (common ancestor -> jpos, one-sided -> hit list).
+MCF_HD void mcf_scan_group(int32_t i0, const int32_t* sz, int32_t pu, int32_t pw, int32_t pmin, int32_t* jpos_slot,
+                           McfScanAcc* acc, McfHit* hits, int32_t hits_cap, McfHit* spill) {
+    // Cheap reject of the whole group first: a subtree can hold pu or pw only if it reaches past the lower
+    // of the two, and almost every position is a small subtree far to the left of both.
+    int32_t zmax = sz[0] > sz[1] ? sz[0] : sz[1];
+    const int32_t z23 = sz[2] > sz[3] ? sz[2] : sz[3];
+    zmax = zmax > z23 ? zmax : z23;
+    if (i0 + 3 + zmax <= pmin) return;
+    for (int e = 0; e < 4; ++e) {
+        const int32_t i = i0 + e;
+        // i <= p < i + size  <=>  unsigned(p - i) < unsigned(size)   (sizes are positive; 0 marks "no position")
+        const bool au = (uint32_t)(pu - i) < (uint32_t)sz[e];
+        const bool aw = (uint32_t)(pw - i) < (uint32_t)sz[e];
+        if (au && aw) MCF_ATOMIC_MAX32(jpos_slot, i);
+        else if (au || aw) {
+            const int32_t slot = MCF_ATOMIC_ADD32(&acc->nhits, 1);
+            const McfHit hrec = (i << 1) | (aw ? 1 : 0);
+            if (slot < hits_cap) hits[slot] = hrec; else spill[slot - hits_cap] = hrec;
+        }
+    }
+}
+
 MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_cap, McfCycle* cy, McfScanAcc* acc,
                            McfHit* hits, int32_t hits_cap, int32_t lane, int32_t nlanes) {
     McfCtx* c = v.ctx;
@@ -690,13 +730,68 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
     const int32_t* psz = c->cur ? v.psz[1] : v.psz[0];
     McfHit* spill = reinterpret_cast<McfHit*>(v.seg);  // scratch the finish pass only fills later; <= n_nodes entries
     const int32_t pu = cy->pu, pw = cy->pw, du = cy->ru.depth, dw = cy->rw.depth;
-    const int32_t pmin = pu < pw ? pu : pw;
+    const int32_t pmin = pu < pw ? pu : pw, pmax = pu > pw ? pu : pw;
     const int32_t base1 = cy->n1, base2 = cy->n2;
     MCF_PSTAMP(4);
-    // groups of four positions, aligned; psz[] is padded so that the group holding max(pu, pw) can be read whole
-    int32_t top = (((pu > pw ? pu : pw) + 1) + 3) & ~3;  // exclusive
-    int32_t par = 0, rounds = 0, jpos = -1;
-    for (;;) {
+    int32_t rounds = 0, jpos = -1;
+    bool done = false;
+    // ---- coarse pass (trees too large for a round or two of the plain sweep): which blocks of 64 positions can hold
+    // an ancestor of either end point?  One pass over reach[0 .. pmax / 64], then only those blocks are looked at:
+    // two dependent round trips whatever the depth of the tree (the plain sweep needs (pmax - pos[join]) / 16 384).
+    if (v.reach && pmax >= 2 * nlanes * 4 * MCF_SCAN_GROUPS) {
+        const int32_t nb = (pmax >> MCF_REACH_SHIFT) + 1;
+        for (int32_t b = lane; b < nb; b += nlanes) {
+            const int32_t r = v.reach[b], s0 = b << MCF_REACH_SHIFT;
+            if ((s0 <= pu && r > pu) || (s0 <= pw && r > pw)) {
+                const int32_t slot = MCF_ATOMIC_ADD32(&acc->nblk, 1);
+                if (slot < MCF_SCAN_BLK_CAP) acc->blk[slot] = b;
+            }
+        }
+        MCF_TEAM_BARRIER();
+        const int32_t nf = acc->nblk;
+        if (nf <= MCF_SCAN_BLK_CAP) {
+            // groups of 16 lanes take one flagged block each: 16 x four positions (one 16-byte load per lane)
+            const int32_t per = MCF_REACH_BLOCK / 4;                    // lanes per block
+            const int32_t ngroups = nlanes >= per ? nlanes / per : 1;
+            const int32_t g = nlanes >= per ? lane / per : 0, sub0 = nlanes >= per ? lane % per : 0;
+            const int32_t nsub = nlanes >= per ? 1 : per;              // a team of one lane walks the block itself
+            for (int32_t t = g; t < nf; t += ngroups) {
+                const int32_t b = acc->blk[t];
+                for (int32_t q = 0; q < nsub; ++q) {
+                    const int32_t i0 = (b << MCF_REACH_SHIFT) + (sub0 + q) * 4;
+                    int32_t sz[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const int4 w4 = *reinterpret_cast<const int4*>(psz + i0);
+                    sz[0] = w4.x; sz[1] = w4.y; sz[2] = w4.z; sz[3] = w4.w;
+#else
+                    for (int e = 0; e < 4; ++e) sz[e] = psz[i0 + e];
+#endif
+                    mcf_scan_group(i0, sz, pu, pw, pmin, &acc->jpos[0], acc, hits, hits_cap, spill);
+                }
+            }
+            MCF_TEAM_BARRIER();
+            jpos = acc->jpos[0];
+            rounds = 2;
+            done = true;
+#if defined(MCF_DEBUG_SCAN) && !defined(__HIP_DEVICE_COMPILE__)
+            {
+                int32_t cnt = 0, jj = -1;
+                for (int32_t i = 0; i <= pmax; ++i) {
+                    const bool au = (uint32_t)(pu - i) < (uint32_t)psz[i], aw = (uint32_t)(pw - i) < (uint32_t)psz[i];
+                    if (au && aw) jj = i; else if (au || aw) ++cnt;
+                    if ((au || aw) && !(v.reach[i >> 6] > (au ? pu : pw))) std::fprintf(stderr, "reach too low: pos %d size %d block %d reach %d pu %d pw %d\n", i, psz[i], i >> 6, v.reach[i >> 6], pu, pw);
+                }
+                if (cnt != acc->nhits || jj != jpos) std::fprintf(stderr, "scan mismatch: hits %d vs %d, join %d vs %d (pu %d pw %d nf %d pivots %lld)\n", acc->nhits, cnt, jpos, jj, pu, pw, nf, (long long)c->pivots);
+            }
+#endif
+        }
+        // (more flagged blocks than the list holds: the plain rounds below redo the search; the hit list is still empty
+        //  because the fine pass did not run)
+    }
+    // ---- plain rounds: groups of four positions, aligned; psz[] is padded so that the group holding max(pu, pw) can be read whole
+    int32_t top = ((pmax + 1) + 3) & ~3;  // exclusive
+    int32_t par = 0;
+    while (!done) {
         const int32_t lo = top - nlanes * 4 * MCF_SCAN_GROUPS;
         int32_t sz[MCF_SCAN_GROUPS][4];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -722,25 +817,7 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
         for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
             const int32_t slice = lo + k * nlanes * 4;
             if (slice + nlanes * 4 <= 0) continue;
-            const int32_t i0 = slice + lane * 4;
-            // Cheap reject of the whole group first: a subtree can hold pu or pw only if it reaches past the lower
-            // of the two, and almost every position is a small subtree far to the left of both.
-            int32_t zmax = sz[k][0] > sz[k][1] ? sz[k][0] : sz[k][1];
-            const int32_t z23 = sz[k][2] > sz[k][3] ? sz[k][2] : sz[k][3];
-            zmax = zmax > z23 ? zmax : z23;
-            if (i0 + 3 + zmax <= pmin) continue;
-            for (int e = 0; e < 4; ++e) {
-                const int32_t i = i0 + e;
-                // i <= p < i + size  <=>  unsigned(p - i) < unsigned(size)   (sizes are positive; 0 marks "no position")
-                const bool au = (uint32_t)(pu - i) < (uint32_t)sz[k][e];
-                const bool aw = (uint32_t)(pw - i) < (uint32_t)sz[k][e];
-                if (au && aw) MCF_ATOMIC_MAX32(&acc->jpos[par], i);
-                else if (au || aw) {
-                    const int32_t slot = MCF_ATOMIC_ADD32(&acc->nhits, 1);
-                    const McfHit hrec = (i << 1) | (aw ? 1 : 0);
-                    if (slot < hits_cap) hits[slot] = hrec; else spill[slot - hits_cap] = hrec;
-                }
-            }
+            mcf_scan_group(slice + lane * 4, sz[k], pu, pw, pmin, &acc->jpos[par], acc, hits, hits_cap, spill);
         }
         MCF_TEAM_BARRIER();
         // the next round's atomics go to the other slot: nobody can overtake a lane still reading this one
@@ -913,6 +990,7 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycl
     c->lo = t < a0 ? t : a0;
     c->hi = t > a0 + S ? t : a0 + S;
     c->nseg = 2 * k + 1;
+    c->nchg = (result == 1 ? n1 : n2) - k - 1;  // the old ancestors of q below the join: their subtrees shrink
     c->apply = 1;
     c->pending_flip = 1;
     c->subtree_nodes += S;
@@ -992,11 +1070,19 @@ MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane,
     const int32_t* opos = result == 1 ? pp.ppos2 : pp.ppos1;
     for (int32_t i = k + 1 + lane; i < nstem_side; i += nlanes) {
         v.node[stem[i]].size = srec[i].size - S;
-        if (v.psz[0]) { const int32_t p = spos[i]; v.psz[0][p] = srec[i].size - S; v.psz[1][p] = srec[i].size - S; }
+        if (v.psz[0]) {
+            const int32_t p = spos[i];
+            v.psz[0][p] = srec[i].size - S; v.psz[1][p] = srec[i].size - S;
+            if (v.reach) v.chg[i - k - 1] = p;  // its block's reach entry may now be too high: the apply pass re-indexes it
+        }
     }
     for (int32_t i = lane; i < nother; i += nlanes) {
         v.node[other[i]].size = orec[i].size + S;
-        if (v.psz[0]) { const int32_t p = opos[i]; v.psz[0][p] = orec[i].size + S; v.psz[1][p] = orec[i].size + S; }
+        if (v.psz[0]) {
+            const int32_t p = opos[i];
+            v.psz[0][p] = orec[i].size + S; v.psz[1][p] = orec[i].size + S;
+            if (v.reach) MCF_ATOMIC_MAX32(&v.reach[p >> MCF_REACH_SHIFT], p + orec[i].size + S);  // must never be too low
+        }
     }
 
     // re-root T2 at u_in: reverse the stem and emit the block permutation.
@@ -1061,7 +1147,8 @@ MCF_HD int32_t mcf_apply_source(const McfCtx& c, const McfSeg* seg, int32_t j, b
 }
 
 // One element of the apply pass (the HIP kernel runs this for a grid-strided j).
-MCF_HD void mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
+// Returns the subtree size now stored at position j (0 when the view keeps none): the apply pass re-indexes reach[] from it.
+MCF_HD int32_t mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
     // selects, not a runtime-indexed member array: a view held in registers must not be
     // forced into private memory
     const int32_t* src = c.cur ? v.order[1] : v.order[0];
@@ -1076,15 +1163,30 @@ MCF_HD void mcf_apply_one(const McfView& v, const McfCtx& c, int32_t j) {
         const int32_t nd = src[i];
         dst[j] = nd;
         pnext[nd] = j;
-        if (zsrc) zdst[j] = zsrc[i];  // subtree sizes travel with their nodes (the finish pass ran before)
+        int32_t z = 0;
+        if (zsrc) { z = zsrc[i]; zdst[j] = z; }  // subtree sizes travel with their nodes (the finish pass ran before)
         if (in_t2) {
             v.pi[nd] += c.sigma;
             if (dd) v.node[nd].depth += dd;
         }
+        return z;
     } else {
         const int32_t nd = src[j];
         dst[j] = nd;  // catch up on what the previous apply changed in the other copy
         pnext[nd] = j;
-        if (zsrc) zdst[j] = zsrc[j];
+        int32_t z = 0;
+        if (zsrc) { z = zsrc[j]; zdst[j] = z; }
+        return z;
     }
+}
+
+// Scalar re-indexing of the coarse blocks one pivot touched (host emulation; the kernels do the same wave-wide inside
+// their apply pass): every block that meets [lo, hi) or the catch-up range, and the blocks of the shrunken subtrees.
+MCF_HD void mcf_reach_reindex_block(const McfView& v, const int32_t* zs, int32_t b) {
+    int32_t m = 0;
+    for (int32_t j = b << MCF_REACH_SHIFT; j < ((b + 1) << MCF_REACH_SHIFT) && j < v.n_nodes; ++j) {
+        const int32_t e = j + zs[j];
+        if (e > m) m = e;
+    }
+    v.reach[b] = m;
 }

@@ -49,7 +49,7 @@ constexpr int kReduceThreads = 256;
 constexpr int kMidMaxNodes = 1 << 13;        // persistent single-workgroup loop (k_solve_mid): auto up to this many nodes ...
 constexpr int kMidMaxArcsPerPivot = MCF_TUNER_MAX_ARCS + 1024;  // ... and this many arcs priced inside the loop per pivot
 constexpr int64_t kIncrementalMinArcs = (int64_t)1 << 22;  // incremental sweeps by default from this many arcs
-constexpr int kScanMaxNodes = 1 << 20;  // beyond this the position-space sizes are not kept: the cycle is always climbed
+constexpr int kScanMaxNodes = 1 << 27;  // (with the coarse index the scan's cost no longer grows with the tree: no practical limit)
 constexpr int kApplyThreads = 256;
 constexpr int kMaxPriceBlocks = 2048;  // 8 workgroups per CU on 256 CUs
 constexpr int kMaxApplyBlocks = 512;
@@ -334,11 +334,47 @@ constexpr int kMaxRcupdBlocks = 1024;
 // posbuf[cur^1], pi and the depths of T2; the update half writes rcache.  One launch boundary less per pivot.
 // `c` is the control block (kernel argument memory / LDS); the pass is spread over `stride` lanes of which this
 // one is `tid`, and over `ngroups` 16-lane groups of which this lane belongs to `group` (sub-lane `sub`).
+__device__ __forceinline__ int32_t wave_max32(int32_t x) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int32_t y = __shfl_xor(x, o); x = y > x ? y : x; }
+    return x;
+}
+
+// `tid` of `stride` lanes, both multiples of 64 apart: whole waves.  With a coarse index (v.reach) every wave takes
+// aligned blocks of 64 positions, so that it holds all 64 new subtree sizes of a block and re-indexes reach[] in the
+// same pass (one wave max + one store per block).
 __device__ __forceinline__ void apply_pass(const McfView& v, const McfCtx& c, int64_t tid, int64_t stride) {
     const int32_t lo = c.lo, hi = c.hi, plo = c.prev_lo, phi = c.prev_hi;
-    for (int64_t j = lo + tid; j < hi; j += stride) mcf_apply_one(v, c, (int32_t)j);
-    for (int64_t j = plo + tid; j < phi; j += stride)
-        if (j < lo || j >= hi) mcf_apply_one(v, c, (int32_t)j);
+    if (!v.reach) {
+        for (int64_t j = lo + tid; j < hi; j += stride) mcf_apply_one(v, c, (int32_t)j);
+        for (int64_t j = plo + tid; j < phi; j += stride)
+            if (j < lo || j >= hi) mcf_apply_one(v, c, (int32_t)j);
+        return;
+    }
+    const int32_t* zsrc = c.cur ? v.psz[1] : v.psz[0];  // the stable old view (outside [lo, hi) old == new)
+    const int32_t lane = (int32_t)(tid & 63);
+    const int64_t gw = tid >> 6, nw = stride >> 6;
+    const int32_t B0 = lo >> MCF_REACH_SHIFT, B1 = hi > lo ? (hi - 1) >> MCF_REACH_SHIFT : B0 - 1;
+    const int32_t P0 = plo >> MCF_REACH_SHIFT, P1 = phi > plo ? (phi - 1) >> MCF_REACH_SHIFT : P0 - 1;
+    auto block = [&](int32_t b, bool moved) {
+        const int32_t j = (b << MCF_REACH_SHIFT) + lane;
+        int32_t z = 0;
+        if (j < v.n_nodes) {
+            const bool in_cur = j >= lo && j < hi, in_prev = j >= plo && j < phi;
+            z = (moved && (in_cur || in_prev)) ? mcf_apply_one(v, c, j) : zsrc[j];
+        }
+        const int32_t m = wave_max32(j < v.n_nodes ? j + z : 0);
+        if (lane == 0) v.reach[b] = m;
+    };
+    for (int64_t b = B0 + gw; b <= B1; b += nw) block((int32_t)b, true);
+    for (int64_t b = P0 + gw; b <= P1; b += nw)
+        if (b < B0 || b > B1) block((int32_t)b, true);
+    // shrunken subtrees outside the moved range: their blocks from the stable view (the finish pass wrote the new
+    // sizes into both copies)
+    for (int64_t t = gw; t < c.nchg; t += nw) {
+        const int32_t b = v.chg[t] >> MCF_REACH_SHIFT;
+        if ((b < B0 || b > B1) && (b < P0 || b > P1)) block(b, false);
+    }
 }
 
 __device__ __forceinline__ void rcupd_pass(const McfView& v, const McfCtx& c, int64_t group, int64_t ngroups, int32_t sub) {
@@ -679,12 +715,7 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
 __global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
     const McfCtx c = *v.ctx;  // uniform: scalar loads
     if (!c.apply) return;
-    const int64_t stride = (int64_t)gridDim.x * kApplyThreads;
-    const int64_t tid = (int64_t)blockIdx.x * kApplyThreads + threadIdx.x;
-    for (int64_t j = c.lo + tid; j < c.hi; j += stride) mcf_apply_one(v, c, (int32_t)j);
-    // catch-up copy of what the previous apply changed in the other buffer
-    for (int64_t j = c.prev_lo + tid; j < c.prev_hi; j += stride)
-        if (j < c.lo || j >= c.hi) mcf_apply_one(v, c, (int32_t)j);
+    apply_pass(v, c, (int64_t)blockIdx.x * kApplyThreads + threadIdx.x, (int64_t)gridDim.x * kApplyThreads);
 }
 
 // ------------------------------------------------------------------ two-lane cycle climb (LDS loop)
@@ -816,6 +847,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
     v.posbuf[1] = reinterpret_cast<int32_t*>(smem + L.pos1);
     v.psz[0] = nullptr;  // always the climb here (see the pivot step); mcf_create keeps no sizes for such a handle
     v.psz[1] = nullptr;
+    v.reach = nullptr;
 
     copy_words(smem + L.tail, g.tail, m_pad4);
     copy_words(smem + L.head, g.head, m_pad4);
@@ -1027,6 +1059,7 @@ struct mcf_handle {
     McfNode *d_rec1 = nullptr, *d_rec2 = nullptr;
     int64_t *d_rcache = nullptr, *d_adj_off = nullptr, *d_adj = nullptr;
     int32_t *d_pos0 = nullptr, *d_pos1 = nullptr, *d_psz0 = nullptr, *d_psz1 = nullptr;
+    int32_t *d_reach = nullptr, *d_chg = nullptr;  // coarse index over the position-space sizes + its scratch
     McfDirty* d_dirty = nullptr;
     int64_t* d_swept = nullptr;  // arcs swept per pricing workgroup (summed by mcf_get_result)
     McfDevex* d_dx = nullptr;        // Devex: granule table + touched-weight list
@@ -1100,9 +1133,19 @@ int upload_image(mcf_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->d_order1, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_pos0, im.pos.data(), im.pos.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_pos1, im.pos.data(), im.pos.size() * 4, hipMemcpyHostToDevice, h->stream));
+    std::vector<int32_t> reach;  // (outlives the asynchronous copy: synchronised at the end of this function)
     if (h->d_psz0) {
         HIP_TRY(h, hipMemcpyAsync(h->d_psz0, im.psize.data(), im.psize.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->d_psz1, im.psize.data(), im.psize.size() * 4, hipMemcpyHostToDevice, h->stream));
+        if (h->d_reach) {
+            const int64_t nb = ((int64_t)im.n_nodes + MCF_REACH_BLOCK - 1) / MCF_REACH_BLOCK;
+            reach.assign((size_t)nb, 0);
+            for (int64_t j = 0; j < im.n_nodes; ++j) {
+                const int32_t end = (int32_t)(j + im.psize[j]);
+                if (end > reach[j >> MCF_REACH_SHIFT]) reach[j >> MCF_REACH_SHIFT] = end;
+            }
+            HIP_TRY(h, hipMemcpyAsync(h->d_reach, reach.data(), reach.size() * 4, hipMemcpyHostToDevice, h->stream));
+        }
     }
     if (h->rcached)
         HIP_TRY(h, hipMemcpyAsync(h->d_rcache, im.rcache.data(), im.m_pad * 8, hipMemcpyHostToDevice, h->stream));
@@ -1279,7 +1322,7 @@ void free_all(mcf_handle* h) {
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
-    (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_dx); (void)hipFree(h->d_full_tab);
+    (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_reach); (void)hipFree(h->d_chg); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_dx); (void)hipFree(h->d_full_tab);
     (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
     if (h->h_one) (void)hipHostFree(h->h_one);
@@ -1398,6 +1441,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
     v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
     v.psz[0] = nullptr; v.psz[1] = nullptr;
+    v.reach = nullptr; v.chg = nullptr;
     v.path1 = h->d_path1; v.path2 = h->d_path2; v.ppos1 = h->d_ppos1; v.ppos2 = h->d_ppos2; v.rec1 = h->d_rec1; v.rec2 = h->d_rec2; v.seg = h->d_seg; v.ctx = h->d_ctx;
 
     {
@@ -1425,10 +1469,14 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     // position-space subtree sizes for the cycle scan: every handle but the LDS-resident ones
     const bool scan_ok = opt.cycle_scan >= 0 && im.n_nodes <= kScanMaxNodes && !h->small;  // -1: never scan
     if (scan_ok) {
-        if ((e = dalloc(&h->d_psz0, N + 4)) != hipSuccess) return fail("hipMalloc psz", e);  // +4: the scan reads whole groups of four
-        if ((e = dalloc(&h->d_psz1, N + 4)) != hipSuccess) return fail("hipMalloc psz", e);
-        if ((e = hipMemset(h->d_psz0, 0, (N + 4) * 4)) != hipSuccess || (e = hipMemset(h->d_psz1, 0, (N + 4) * 4)) != hipSuccess) return fail("hipMemset psz", e);
+        const size_t NP = (N + MCF_REACH_BLOCK - 1) / MCF_REACH_BLOCK * MCF_REACH_BLOCK + 4;  // whole coarse blocks (+4: groups of four)
+        if ((e = dalloc(&h->d_psz0, NP)) != hipSuccess) return fail("hipMalloc psz", e);
+        if ((e = dalloc(&h->d_psz1, NP)) != hipSuccess) return fail("hipMalloc psz", e);
+        if ((e = hipMemset(h->d_psz0, 0, NP * 4)) != hipSuccess || (e = hipMemset(h->d_psz1, 0, NP * 4)) != hipSuccess) return fail("hipMemset psz", e);
         v.psz[0] = h->d_psz0; v.psz[1] = h->d_psz1;
+        if ((e = dalloc(&h->d_reach, NP / MCF_REACH_BLOCK + 1)) != hipSuccess) return fail("hipMalloc reach", e);
+        if ((e = dalloc(&h->d_chg, N)) != hipSuccess) return fail("hipMalloc chg", e);
+        v.reach = h->d_reach; v.chg = h->d_chg;
     }
     // cycle search: how many round trips the one-lane climb takes before the workgroup-wide scan over
     // preorder positions finishes the cycle.  Auto = none: measured on MI355X (profiles/r01_f_*), scanning
@@ -1440,8 +1488,12 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     // resident reduced costs for everything that does not take the fused LDS path
     h->rcached = !h->small && !opt.no_rcache && im.m > 0;
     if (h->rcached) {
-        mcf_build_rcache(h->im, h->shard, h->shards);
-        v.rc_partial = h->shards > 1 ? 1 : 0;
+        // a rank patches only the reduced costs it sweeps -- for the rules whose sweeps cover a FIXED share of every bucket.
+        // Devex cuts the block first and the shard second (so that the union over ranks does not depend on the rank
+        // count), and blocks move and resize: there every rank keeps all reduced costs exact, as a single GPU does.
+        const bool partial = h->shards > 1 && opt.rule != MCF_RULE_DEVEX_BLOCK;
+        mcf_build_rcache(h->im, partial ? h->shard : 0, partial ? h->shards : 1);
+        v.rc_partial = partial ? 1 : 0;
         if ((e = dalloc(&h->d_rcache, im.m_pad)) != hipSuccess) return fail("hipMalloc rcache", e);
         if ((e = dalloc(&h->d_adj_off, im.adj_off.size())) != hipSuccess) return fail("hipMalloc adj_off", e);
         if ((e = dalloc(&h->d_adj, im.adj.size())) != hipSuccess) return fail("hipMalloc adj", e);
@@ -1907,7 +1959,7 @@ int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident) {
     if (h->rcached) {
         std::vector<int64_t> rc(im.m_pad);
         HIP_TRY(h, hipMemcpy(rc.data(), h->d_rcache, rc.size() * 8, hipMemcpyDeviceToHost));
-        if (h->shards > 1) {  // a sharded handle keeps only its own shard exact: the other arcs from the potentials
+        if (h->view.rc_partial) {  // a sharded handle keeps only its own shard exact: the other arcs from the potentials
             std::vector<int64_t> pi(im.n_nodes);
             HIP_TRY(h, hipMemcpy(pi.data(), h->d_pi, pi.size() * 8, hipMemcpyDeviceToHost));
             std::vector<int8_t> mine(im.m, 0);

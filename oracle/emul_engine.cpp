@@ -21,7 +21,7 @@ namespace {
 
 struct Emul {
     McfHostImage im;
-    std::vector<int32_t> order1, path1, path2, pos1, psz1, ppos1, ppos2;
+    std::vector<int32_t> order1, path1, path2, pos1, psz1, ppos1, ppos2, reach, chg;
     std::vector<McfNode> rec1, rec2;
     std::vector<McfSeg> seg;
     McfCtx ctx;
@@ -79,10 +79,17 @@ void bind(Emul& e) {
     v.dirty = nullptr;  // the emulation always sweeps everything: an independent check of the incremental sweeps
     v.posbuf[0] = im.pos.data();
     v.posbuf[1] = e.pos1.data();
-    im.psize.resize((size_t)im.n_nodes + 4, 0);  // the scan reads whole groups of four positions
+    const size_t np = ((size_t)im.n_nodes + MCF_REACH_BLOCK - 1) / MCF_REACH_BLOCK * MCF_REACH_BLOCK + 4;
+    im.psize.resize(np, 0);  // the scan reads whole coarse blocks / groups of four positions
     e.psz1 = im.psize;
     v.psz[0] = im.psize.data();
     v.psz[1] = e.psz1.data();
+    // coarse index over the sizes (see McfView::reach); the emulation keeps it exact
+    e.reach.assign(np / MCF_REACH_BLOCK + 1, 0);
+    e.chg.assign(im.n_nodes, 0);
+    v.reach = e.reach.data();
+    v.chg = e.chg.data();
+    for (int32_t b = 0; b < (im.n_nodes + MCF_REACH_BLOCK - 1) / MCF_REACH_BLOCK; ++b) mcf_reach_reindex_block(v, v.psz[0], b);
 }
 
 // scalar stand-in for the pricing kernel: shard r of G, Devex block = ctx.block_index of
@@ -136,6 +143,32 @@ int64_t price_minor(Emul& e, const McfCand* cands, int64_t ncand, int64_t* key, 
     return ncand;
 }
 
+// the apply pass of one pivot (k_update's permutation half), then the coarse blocks it touched are re-indexed
+void apply_all(Emul& e) {
+    McfCtx& c = e.ctx;
+    if (!c.apply) return;
+    // the two ranges the apply kernel covers: this pivot's and the stale one
+    for (int32_t j = c.lo; j < c.hi; ++j) mcf_apply_one(e.view, c, j);
+    for (int32_t j = c.prev_lo; j < c.prev_hi; ++j)
+        if (j < c.lo || j >= c.hi) mcf_apply_one(e.view, c, j);
+    if (!e.view.reach) return;
+    const int32_t* znew = c.cur ? e.view.psz[0] : e.view.psz[1];  // the copy the pass just wrote
+    auto range = [&](int32_t lo, int32_t hi) {
+        if (hi <= lo) return;
+        for (int32_t b = lo >> MCF_REACH_SHIFT; b <= (hi - 1) >> MCF_REACH_SHIFT; ++b) mcf_reach_reindex_block(e.view, znew, b);
+    };
+    range(c.lo, c.hi);
+    range(c.prev_lo, c.prev_hi);
+    // shrunken subtrees elsewhere: their blocks too (block-wise like the kernels: a block that meets one of the two
+    // ranges was re-indexed above, from the copy that holds its new arrangement)
+    auto meets = [&](int32_t b, int32_t lo, int32_t hi) { return hi > lo && b >= (lo >> MCF_REACH_SHIFT) && b <= ((hi - 1) >> MCF_REACH_SHIFT); };
+    for (int32_t t = 0; t < c.nchg; ++t) {
+        const int32_t b = e.view.chg[t] >> MCF_REACH_SHIFT;
+        if (meets(b, c.lo, c.hi) || meets(b, c.prev_lo, c.prev_hi)) continue;
+        mcf_reach_reindex_block(e.view, znew, b);   // (outside both ranges the two copies agree)
+    }
+}
+
 void init_blocks(Emul& e, int64_t block_size) {
     McfCtx& c = e.ctx;
     const int64_t m = e.im.m;
@@ -186,12 +219,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         if (c.pivots < c.max_pivots) c.arcs_priced += priced;
         if (trace_arcs && ntrace < trace_cap) trace_arcs[ntrace++] = arc < 0 ? -1 : ((arc >> 32) & (MCF_DIR_FLAG - 1));
         mcf_pivot_seq(e.view, key, arc, rule);
-        if (c.apply) {
-            // the two ranges the apply kernel covers: this pivot's and the stale one
-            for (int32_t j = c.lo; j < c.hi; ++j) mcf_apply_one(e.view, c, j);
-            for (int32_t j = c.prev_lo; j < c.prev_hi; ++j)
-                if (j < c.lo || j >= c.hi) mcf_apply_one(e.view, c, j);
-        }
+        apply_all(e);
     }
     if (c.pending_flip) { c.cur ^= 1; c.pending_flip = 0; }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -291,11 +319,7 @@ void emul_pivot(void* h, const int64_t* cands, int32_t ncand) {
         if (mcf_cand_better(kk, cands[2 * i + 1], key, arc)) { key = kk; arc = cands[2 * i + 1]; }
     }
     mcf_pivot_seq(e->view, key, arc, e->rule);
-    if (c.apply) {
-        for (int32_t j = c.lo; j < c.hi; ++j) mcf_apply_one(e->view, c, j);
-        for (int32_t j = c.prev_lo; j < c.prev_hi; ++j)
-            if (j < c.lo || j >= c.hi) mcf_apply_one(e->view, c, j);
-    }
+    apply_all(*e);
 }
 
 // `count` pivot slots on one gathered list (mcf_enqueue_pivots): the first takes the sweep's keys unless minor iterations
