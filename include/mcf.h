@@ -96,7 +96,10 @@ typedef struct mcf_options {
                                 reference's min-cost entering rule for assignment problems (specialized_pivots.py:191-223) followed
                                 by its general pricing for what is left (simplex.py:1061-1064).  The row-scan rule it uses for
                                 transportation problems (specialized_pivots.py:69-117) IS MCF_RULE_DANTZIG_FULL. */
-    int32_t reserved[3];     /* must be 0 */
+    int32_t compressed_keys; /* Dantzig / candidate-list grid sweeps over 4-byte key codes (one per arc, kept exact next to the resident
+                                reduced costs) instead of 8 B reduced cost + 1 B state: 0 = auto (on), -1 = off */
+    int32_t vkey_half_log2;  /* test hook: log2 of the half width of a code level (0 = 28); small values force the exact-compare path */
+    int32_t reserved[1];     /* must be 0 */
 } mcf_options;
 
 typedef struct mcf_stats {
@@ -218,6 +221,11 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
  * when the handle keeps one (*resident = 1), else cost + pi[tail] - pi[head] computed on the host.
  * Tests use it to check the invariant resident rc == cost + pi[tail] - pi[head]. */
 int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident);
+
+/* The compressed Dantzig key of every arc (caller's order) as the sweep reads it; *present = 0 (and zeros) when the
+ * handle keeps none.  Tests check the invariant key == code(-state * reduced cost) and decode it with the documented
+ * scheme (csrc/mcf_core.h: mcf_vkey). */
+int mcf_get_pricing_keys(mcf_handle* h, int32_t* keys_out, int32_t* present);
 
 /* Devex reference weights of every arc (caller's order; 1.0 for a handle that never priced with the Devex rule).
  * With mcf_get_tree / mcf_get_result this is the full input of one block selection, so that a test can replay

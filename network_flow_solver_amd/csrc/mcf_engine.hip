@@ -319,6 +319,85 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
     }
 }
 
+// ------------------------------------------------------------------ k_price_v: Dantzig sweep over COMPRESSED keys
+// 4 bytes per arc (McfView::vkey, see mcf_core.h) instead of 8 B reduced cost + 1 B state: the sweep is HBM-bound at
+// scale, so bytes are time.  Same arc sets, same arg-max, same tie rule as k_price_rc<DANTZIG>: a code orders like the
+// violation it stands for and equal codes mean equal violations; an arc whose violation does not fit the code
+// (MCF_VKEY_SAT) is compared by its exact value, fetched on the spot.  The workgroup's candidate carries the exact
+// violation (one look-up per lane at the end, together with the caller's arc id), so k_pivot / k_reduce see what
+// they always saw.
+template <bool INC>
+__global__ __launch_bounds__(kPriceThreads) void k_price_v(McfView v, int64_t shard, int64_t shards, int use_block,
+                                                            McfCand* __restrict__ cand, int64_t* __restrict__ swept,
+                                                            const int32_t* __restrict__ blk_tab) {
+    const McfCtx* c = v.ctx;
+    const int x = blockIdx.x & (MCF_NUM_BUCKETS - 1);
+    const int64_t lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+    const int4* __restrict__ vk4 = reinterpret_cast<const int4*>(v.vkey);
+    const int32_t* __restrict__ orig = v.orig;
+    const int64_t stride = nlb * kPriceThreads;
+    constexpr int U = 8;   // 16-byte loads in flight per lane (4 arcs each)
+    int4 q[U];
+    int64_t lo, hi;
+    if (blk_tab) { lo = blk_tab[x * 2]; hi = blk_tab[x * 2 + 1]; }
+    else mcf_bucket_slice(v.bucket_off, x, shard, shards, 0, 1, &lo, &hi);
+    const int64_t g_lo = lo >> 2, g_hi = (hi + 3) >> 2;  // groups of 4 arcs
+    auto load_batch = [&](int64_t g0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t g = g0 + u * stride;
+            q[u] = g < g_hi ? vk4[g] : make_int4(0, 0, 0, 0);
+        }
+    };
+    int64_t g0 = g_lo + lb * kPriceThreads + threadIdx.x;
+    if (g0 < g_hi) load_batch(g0);   // before the control block is looked at: a full sweep's slice does not depend on it
+    if (use_block == 2 && (c->minor_left > 0 || c->status != MCF_RUNNING)) return;   // candidate list still live
+    if (INC && v.dirty && (c->status != MCF_RUNNING || !v.dirty->flag[blockIdx.x])) return;  // clean block: candidate stands
+    int32_t best = 0;      // best code of this lane
+    int64_t best_i = -1;   // its engine arc
+    int64_t best_x = 0;    // exact violation, kept only while best == MCF_VKEY_SAT
+    auto exact = [&](int64_t i) { return -(int64_t)v.state[i] * v.rcache[i]; };
+    if (c->status == MCF_RUNNING) {
+        if (INC && swept && threadIdx.x == 0) {
+            const uint32_t ng = (uint32_t)(g_hi - g_lo), per = (uint32_t)nlb * 256u, full = ng / per, rem = ng - full * per;
+            const uint32_t off = (uint32_t)lb * 256u;
+            const uint32_t mine = full * 256u + (rem > off ? (rem - off < 256u ? rem - off : 256u) : 0u);
+            atomicAdd(reinterpret_cast<unsigned long long*>(swept) + blockIdx.x, (unsigned long long)mine * 4ull);
+        }
+        while (g0 < g_hi) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int32_t ks[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                const int64_t g = g0 + u * stride;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t kk = ks[k];
+                    if (kk < best || kk == 0) continue;
+                    const int64_t i = (g << 2) + k;
+                    if (i < lo || i >= hi) continue;
+                    if (kk > best) { best = kk; best_i = i; if (kk == MCF_VKEY_SAT) best_x = exact(i); }
+                    else if (kk == MCF_VKEY_SAT) {   // both beyond the code: exact comparison
+                        const int64_t xv = exact(i);
+                        if (xv > best_x || (xv == best_x && orig[i] < orig[best_i])) { best_x = xv; best_i = i; }
+                    } else if (orig[i] < orig[best_i]) best_i = i;   // equal codes = equal violations: lowest caller's index
+                }
+            }
+            g0 += stride * U;
+            if (g0 < g_hi) load_batch(g0);
+        }
+    }
+    int64_t key = 0, arc = -1;
+    if (best_i >= 0) {
+        key = best == MCF_VKEY_SAT ? best_x : exact(best_i);
+        arc = mcf_pack_arc(orig[best_i], best_i);
+    }
+    block_argmax<kPriceThreads>(key, arc);
+    if (threadIdx.x == 0) {
+        cand[blockIdx.x] = McfCand{key, arc};
+        if (INC && v.dirty && c->status == MCF_RUNNING) v.dirty->flag[blockIdx.x] = 0;
+    }
+}
+
 // ------------------------------------------------------------------ keeping the resident reduced costs exact
 // The swap shifted the potentials of the re-hung subtree T2 by sigma, so an arc changes iff exactly
 // one end point is in T2: +sigma when its tail is inside, -sigma when its head is.  16 lanes per T2
@@ -394,7 +473,10 @@ __device__ __forceinline__ void rcupd_pass(const McfView& v, const McfCtx& c, in
             const int32_t pw = pold[(int32_t)(ent >> 32)];
             if (pw >= a0 && pw < a0 + S) continue;  // both ends inside T2: unchanged
             const int32_t e = (int32_t)((uint32_t)ent >> 1);
-            rcache[e] += (ent & 1) ? sigma : -sigma;
+            const int64_t r = rcache[e] + ((ent & 1) ? sigma : -sigma);
+            rcache[e] = r;
+            // the compressed key follows (the finish pass has already given the entering / leaving arc its new state)
+            if (v.vkey) v.vkey[e] = mcf_vkey(-(int64_t)v.state[e] * r, v.vk_bigm, v.vk_half);
             mcf_mark_dirty(v, e);
         }
     }
@@ -1058,6 +1140,7 @@ struct mcf_handle {
     int32_t *d_order0 = nullptr, *d_order1 = nullptr, *d_path1 = nullptr, *d_path2 = nullptr, *d_ppos1 = nullptr, *d_ppos2 = nullptr;
     McfNode *d_rec1 = nullptr, *d_rec2 = nullptr;
     int64_t *d_rcache = nullptr, *d_adj_off = nullptr, *d_adj = nullptr;
+    int32_t* d_vkey = nullptr;   // compressed Dantzig keys (4 B per arc), see McfView::vkey
     int32_t *d_pos0 = nullptr, *d_pos1 = nullptr, *d_psz0 = nullptr, *d_psz1 = nullptr;
     int32_t *d_reach = nullptr, *d_chg = nullptr;  // coarse index over the position-space sizes + its scratch
     McfDirty* d_dirty = nullptr;
@@ -1149,6 +1232,12 @@ int upload_image(mcf_handle* h) {
     }
     if (h->rcached)
         HIP_TRY(h, hipMemcpyAsync(h->d_rcache, im.rcache.data(), im.m_pad * 8, hipMemcpyHostToDevice, h->stream));
+    std::vector<int32_t> vk;  // (synchronised before this function returns)
+    if (h->d_vkey) {
+        vk.assign(im.m_pad, 0);
+        for (int64_t e = 0; e < im.m; ++e) vk[e] = mcf_vkey(-(int64_t)im.state[e] * im.rcache[e], h->view.vk_bigm, h->view.vk_half);
+        HIP_TRY(h, hipMemcpyAsync(h->d_vkey, vk.data(), vk.size() * 4, hipMemcpyHostToDevice, h->stream));
+    }
     if (h->d_dirty) HIP_TRY(h, hipMemsetAsync(h->d_dirty->flag, 1, sizeof(h->d_dirty->flag), h->stream));  // every block is due (any non-zero word)
     if (h->d_swept) HIP_TRY(h, hipMemsetAsync(h->d_swept, 0, kMaxPriceBlocks * sizeof(int64_t), h->stream));
     McfCtx c;
@@ -1210,7 +1299,10 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
     const int64_t z = 0;
     // use_block: 0 = whole shard, 1 = current Devex block, 2 = whole shard unless minor iterations are pending
     if (rule == MCF_RULE_CANDIDATE_LIST && use_block) use_block = 2;
-    if (h->rcached) {
+    if (h->rcached && v.vkey && rule != MCF_RULE_DEVEX_BLOCK) {
+        if (v.dirty) hipLaunchKernelGGL((k_price_v<true>), grid, block, 0, s, v, h->shard, h->shards, use_block, out, swept, (const int32_t*)h->d_full_tab);
+        else hipLaunchKernelGGL((k_price_v<false>), grid, block, 0, s, v, h->shard, h->shards, use_block, out, swept, (const int32_t*)h->d_full_tab);
+    } else if (h->rcached) {
         if (rule == MCF_RULE_DEVEX_BLOCK)
             hipLaunchKernelGGL((k_price_rc<MCF_RULE_DEVEX_BLOCK, false, false>), grid, block, 0, s, v, h->shard, h->shards, use_block, z, z, out, swept, (const int32_t*)nullptr);
         else
@@ -1323,7 +1415,7 @@ void free_all(mcf_handle* h) {
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
     (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_reach); (void)hipFree(h->d_chg); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_dx); (void)hipFree(h->d_full_tab);
-    (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj);
+    (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj); (void)hipFree(h->d_vkey);
     if (h->h_ctx) (void)hipHostFree(h->h_ctx);
     if (h->h_one) (void)hipHostFree(h->h_one);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1521,6 +1613,14 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         }
         const bool fits = im.n_nodes <= kMidMaxNodes && per_pivot_arcs <= kMidMaxArcsPerPivot;
         h->mid = h->rcached && scan_ok && h->shards == 1 && !opt.profile && opt.mid_loop >= 0 && (fits || opt.mid_loop > 0);
+    }
+    // compressed Dantzig keys for the grid sweeps of the Dantzig / candidate-list rules (4 B per arc instead of 9)
+    v.vkey = nullptr;
+    v.vk_bigm = im.big_m;
+    v.vk_half = 1 << (opt.vkey_half_log2 > 0 && opt.vkey_half_log2 <= 28 ? opt.vkey_half_log2 : 28);
+    if (h->rcached && !h->mid && opt.rule != MCF_RULE_DEVEX_BLOCK && !opt.forward_first && opt.compressed_keys >= 0) {
+        if ((e = dalloc(&h->d_vkey, im.m_pad)) != hipSuccess) return fail("hipMalloc vkey", e);
+        v.vkey = h->d_vkey;
     }
     // incremental pricing for the rules whose sweeps cover the whole shard (Dantzig, candidate list); not for the
     // persistent loop, whose instances are far too small for it (its kernel compiles the marking away)
@@ -1977,6 +2077,19 @@ int mcf_get_reduced_costs(mcf_handle* h, int64_t* rc_out, int32_t* resident) {
         HIP_TRY(h, hipMemcpy(pi.data(), h->d_pi, pi.size() * 8, hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < im.m; ++i) rc_out[im.orig[i]] = im.cost64[i] + pi[im.tail[i]] - pi[im.head[i]];
     }
+    return MCF_OK;
+}
+
+int mcf_get_pricing_keys(mcf_handle* h, int32_t* keys_out, int32_t* present) {
+    if (!h || !keys_out) return MCF_E_BAD_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const McfHostImage& im = h->im;
+    if (present) *present = h->d_vkey ? 1 : 0;
+    if (!h->d_vkey) { for (int64_t i = 0; i < im.m; ++i) keys_out[i] = 0; return MCF_OK; }
+    std::vector<int32_t> vk(im.m_pad);
+    HIP_TRY(h, hipMemcpy(vk.data(), h->d_vkey, vk.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < im.m; ++i) keys_out[im.orig[i]] = vk[i];
     return MCF_OK;
 }
 

@@ -30,7 +30,7 @@ CAP_INF = -1
 ABI_SYMBOLS = (
     "mcf_default_options", "mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis",
     "mcf_enqueue_price", "mcf_enqueue_pivot", "mcf_shard_info", "mcf_enqueue_price_list", "mcf_enqueue_pivots", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing",
-    "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_get_weights", "mcf_dimacs_scan", "mcf_dimacs_load", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
+    "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_get_pricing_keys", "mcf_get_weights", "mcf_dimacs_scan", "mcf_dimacs_load", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
 )
 
 
@@ -54,7 +54,7 @@ class McfOptions(ctypes.Structure):
         ("price_blocks", ctypes.c_int32), ("no_fused", ctypes.c_int32), ("no_rcache", ctypes.c_int32),
         ("cycle_scan", ctypes.c_int32), ("mid_loop", ctypes.c_int32), ("full_sweeps", ctypes.c_int32),
         ("devex_tuner", ctypes.c_int32), ("devex_stay", ctypes.c_int32), ("forward_first", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 3),
+        ("compressed_keys", ctypes.c_int32), ("vkey_half_log2", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1),
     ]
 
 
@@ -115,6 +115,7 @@ def load_library():
     lib.mcf_get_tree.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i8p, i64p, i32p, i32p]
     lib.mcf_get_reduced_costs.argtypes = [vp, i64p, i32p]
     lib.mcf_get_weights.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.mcf_get_pricing_keys.argtypes = [vp, i32p, i32p]
     lib.mcf_dimacs_scan.argtypes = [ctypes.c_char_p, i64p, i64p, ctypes.c_char_p, ctypes.c_int32]
     lib.mcf_dimacs_load.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, i64p,
                                     ctypes.c_char_p, ctypes.c_int32]
@@ -124,7 +125,7 @@ def load_library():
     lib.mcf_destroy.restype = None
     for name in ("mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis", "mcf_enqueue_price",
                  "mcf_enqueue_pivot", "mcf_shard_info", "mcf_enqueue_price_list", "mcf_enqueue_pivots", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing", "mcf_time_copy",
-                 "mcf_get_tree", "mcf_get_reduced_costs", "mcf_get_weights", "mcf_dimacs_scan", "mcf_dimacs_load"):
+                 "mcf_get_tree", "mcf_get_reduced_costs", "mcf_get_pricing_keys", "mcf_get_weights", "mcf_dimacs_scan", "mcf_dimacs_load"):
         getattr(lib, name).restype = ctypes.c_int
     if lib.mcf_abi_version() != ABI_VERSION:
         raise EngineUnavailableError("libmcf_hip.so ABI version mismatch")
@@ -157,7 +158,8 @@ class McfEngine:
                  batch_pivots: int = 64, use_graph: bool = True, profile: bool = False, device: int = -1,
                  shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
                  resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0, full_sweeps: int = 0,
-                 devex_tuner: int = 0, devex_stay: bool = False, forward_first: bool = False):
+                 devex_tuner: int = 0, devex_stay: bool = False, forward_first: bool = False, compressed_keys: int = 0,
+                 vkey_half_log2: int = 0):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -192,6 +194,8 @@ class McfEngine:
         opt.devex_tuner = int(devex_tuner)   # 0 auto (on unless block_size is given), 1 on, -1 off
         opt.devex_stay = 1 if devex_stay else 0
         opt.forward_first = 1 if forward_first else 0
+        opt.compressed_keys = int(compressed_keys)   # 0 auto (on for the Dantzig-key grid sweeps), -1 off
+        opt.vkey_half_log2 = int(vkey_half_log2)
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule
@@ -314,6 +318,13 @@ class McfEngine:
         res = ctypes.c_int32(0)
         self._check(self._lib.mcf_get_reduced_costs(self._h, _p(rc, ctypes.c_int64), ctypes.byref(res)))
         return rc[: self.m], bool(res.value)
+
+    def pricing_keys(self):
+        """(compressed Dantzig key per arc in caller order, present?) -- what k_price_v reads."""
+        k = np.zeros(max(self.m, 1), dtype=np.int32)
+        present = ctypes.c_int32(0)
+        self._check(self._lib.mcf_get_pricing_keys(self._h, _p(k, ctypes.c_int32), ctypes.byref(present)))
+        return k[: self.m], bool(present.value)
 
     def weights(self) -> np.ndarray:
         """Devex reference weights per arc (caller's order)."""

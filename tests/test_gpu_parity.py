@@ -99,6 +99,61 @@ def test_resident_reduced_costs_stay_exact(gpu_engine_module, rule, mid_loop):
     assert np.array_equal(tree["order"], rtree["order"]) and res.stats["arcs_priced"] == ref.stats["arcs_priced"]
 
 
+def _vkey_code(viol: np.ndarray, bigm: int, half: int) -> np.ndarray:
+    """csrc/mcf_core.h:mcf_vkey in numpy: the compressed Dantzig key of a violation."""
+    SAT = 0x7fffffff
+    viol = viol.astype(np.int64)
+    if bigm < (1 << 29) and half >= (1 << 28):
+        return np.where(viol <= 0, 0, np.where(viol < SAT, viol, SAT)).astype(np.int32)
+    j = np.where(2 * viol < bigm, 0, np.where(2 * viol < 3 * bigm, 1, np.where(2 * viol < 5 * bigm, 2, 3)))
+    d = viol - j * bigm
+    ok = (j < 3) & (d < half) & (d > -half)
+    code = (j.astype(np.int64) << 29) + d + (1 << 28)
+    return np.where(viol <= 0, 0, np.where(ok, code, SAT)).astype(np.int32)
+
+
+@pytest.mark.parametrize("rule", [0, 2], ids=["dantzig", "candidate_list"])
+@pytest.mark.parametrize("variant", ["plain", "levels", "levels_narrow", "narrow"])
+def test_compressed_pricing_keys(gpu_engine_module, rule, variant):
+    """The Dantzig / candidate-list grid sweep reads 4-byte key codes (k_price_v) instead of reduced cost + state.
+    Invariant at several stages of a solve: code == mcf_vkey(-state * rc) for every arc; and the pivot sequence equals
+    the one of the uncompressed sweep (and of the CPU emulation) -- also when big-M forces the level coding (costs up
+    to 2 * 10^6 on 1 024 nodes: big-M ~ 2 * 10^9) and when a narrow level width pushes most arcs into the
+    exact-compare path (MCF_VKEY_SAT)."""
+    e = gpu_engine_module
+    _, inst = load_synthetic()[7]                                  # 1 024 nodes / 8 192 arcs
+    cost = inst.cost if variant in ("plain", "narrow") else inst.cost * 200
+    half_log2 = {"plain": 0, "levels": 0, "levels_narrow": 12, "narrow": 10}[variant]
+    bigm = (int(np.abs(cost).max()) + 1) * (inst.n + 2)
+    assert (bigm >= 1 << 29) == (variant.startswith("levels"))
+    kw = dict(rule=rule, fused=False, mid_loop=-1, full_sweeps=-1 if rule == 0 else 1)
+    sat_seen = 0
+    with e.McfEngine(inst.n, inst.tail, inst.head, cost, inst.cap, inst.supply, vkey_half_log2=half_log2, **kw) as eng:
+        for budget in (0, 1, 5, 40, 300, 10 ** 9):
+            if budget:
+                eng.solve(max_pivots=budget)
+            keys, present = eng.pricing_keys()
+            assert present
+            t = eng.tree()
+            rc = cost + t["pi"][inst.tail] - t["pi"][inst.head]
+            want = _vkey_code(-(t["state"].astype(np.int64)) * rc, bigm, 1 << (half_log2 or 28))
+            assert np.array_equal(keys, want)
+            sat_seen += int((keys == 0x7fffffff).sum())
+        res, tree = eng.result(), eng.tree()
+    with e.McfEngine(inst.n, inst.tail, inst.head, cost, inst.cap, inst.supply, compressed_keys=-1, **kw) as eng:
+        assert not eng.pricing_keys()[1]
+        eng.solve()
+        ref, rtree = eng.result(), eng.tree()
+    em = oracle.emul_solve(inst.n, inst.tail, inst.head, cost, inst.cap, inst.supply, rule=rule)
+    assert res.status == ref.status == "optimal" and res.stats["pivots"] == ref.stats["pivots"]
+    assert np.array_equal(res.flow, ref.flow) and np.array_equal(res.potential, ref.potential)
+    assert np.array_equal(tree["order"], rtree["order"])
+    if rule == 0:
+        assert res.stats["pivots"] == em["pivots"] and np.array_equal(res.flow, em["flow"])
+    if variant in ("levels_narrow", "narrow"):
+        assert sat_seen > 0                                         # the exact-compare path really ran
+
+
 @pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
 @pytest.mark.parametrize("idx", [3, 6, 7], ids=["netgen256", "goto256", "netgen1024"])
 def test_cycle_scan_equals_cycle_climb(gpu_engine_module, idx, rule):
