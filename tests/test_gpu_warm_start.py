@@ -44,6 +44,35 @@ CASES = [
                ("n3", "n4", 10.0, 10.0)]),
      Basis(tree_arcs={("n0", "n1"), ("n2", "n3"), ("n4", "n5")},
            arc_flows={("n0", "n1"): 10.0, ("n2", "n3"): 8.0, ("n4", "n5"): 5.0}), "optimal", 23.0),
+    ("cost_change:239-275",
+     _problem([("s", 10.0), ("m", 0.0), ("t", -10.0)], [("s", "m", 20.0, 1.0), ("m", "t", 20.0, 1.0), ("s", "t", 20.0, 5.0)]),
+     _problem([("s", 10.0), ("m", 0.0), ("t", -10.0)], [("s", "m", 20.0, 3.0), ("m", "t", 20.0, 3.0), ("s", "t", 20.0, 1.0)]),
+     None, "optimal", 10.0),
+    ("add_arc:277-315",
+     _problem([("s", 10.0), ("m", 0.0), ("t", -10.0)], [("s", "m", 20.0, 2.0), ("m", "t", 20.0, 2.0)]),
+     _problem([("s", 10.0), ("m", 0.0), ("t", -10.0)], [("s", "m", 20.0, 2.0), ("m", "t", 20.0, 2.0), ("s", "t", 20.0, 1.0)]),
+     None, "optimal", 10.0),
+    ("remove_arc:317-353",
+     _problem([("s", 10.0), ("m", 0.0), ("t", -10.0)], [("s", "m", 20.0, 2.0), ("m", "t", 20.0, 2.0), ("s", "t", 20.0, 1.0)]),
+     _problem([("s", 10.0), ("m", 0.0), ("t", -10.0)], [("s", "m", 20.0, 2.0), ("m", "t", 20.0, 2.0)]),
+     None, "optimal", 40.0),
+    ("multi_commodity_style:427-459",
+     _problem([("s1", 30.0), ("s2", 40.0), ("m", 0.0), ("t1", -35.0), ("t2", -35.0)],
+              [("s1", "m", 50.0, 1.0), ("s2", "m", 50.0, 1.0), ("m", "t1", 50.0, 1.0), ("m", "t2", 50.0, 1.0)]),
+     _problem([("s1", 30.0), ("s2", 40.0), ("m", 0.0), ("t1", -35.0), ("t2", -35.0)],
+              [("s1", "m", 60.0, 1.0), ("s2", "m", 50.0, 1.0), ("m", "t1", 50.0, 1.0), ("m", "t2", 50.0, 1.0)]),
+     None, "optimal", 140.0),
+    ("with_cycles:461-492",
+     _problem([("s", 10.0), ("a", 0.0), ("b", 0.0), ("t", -10.0)],
+              [("s", "a", 20.0, 1.0), ("a", "b", 20.0, 1.0), ("b", "a", 20.0, 2.0), ("a", "t", 20.0, 1.0)]),
+     _problem([("s", 10.0), ("a", 0.0), ("b", 0.0), ("t", -10.0)],
+              [("s", "a", 20.0, 2.0), ("a", "b", 20.0, 1.0), ("b", "a", 20.0, 2.0), ("a", "t", 20.0, 2.0)]),
+     None, "optimal", 40.0),
+    ("disconnected_components:556-606", None,
+     _problem([("s1", 20.0), ("t1", -20.0), ("s2", 15.0), ("t2", -15.0), ("m1", 0.0), ("m2", 0.0)],
+              [("s1", "m1", 20.0, 1.0), ("m1", "t1", 20.0, 1.0), ("s2", "m2", 15.0, 1.0), ("m2", "t2", 15.0, 1.0),
+               ("m1", "m2", 10.0, 5.0)]),
+     Basis(tree_arcs={("s1", "m1"), ("m1", "t1")}, arc_flows={("s1", "m1"): 20.0, ("m1", "t1"): 20.0}), "optimal", 70.0),
     ("single_arc_basis:653-686", None,
      _problem([("a", 15.0), ("b", 0.0), ("c", 0.0), ("d", -15.0)],
               [("a", "b", 15.0, 1.0), ("b", "c", 15.0, 1.0), ("c", "d", 15.0, 1.0), ("a", "d", 10.0, 4.0)]),
@@ -66,6 +95,35 @@ def test_reference_warm_start_scenarios(gpu_engine_module, name, first, second, 
     assert (cold.status, cold.objective, cold.flows) == (r2.status, r2.objective, r2.flows)
     if name.startswith("identical"):
         assert r2.iterations <= r1.iterations
+
+
+def test_none_basis_is_a_cold_start(gpu_engine_module):
+    """test_warm_start.py:22-40."""
+    r = nfs.solve_min_cost_flow(_problem(ST, [("s", "t", 20.0, 1.0)]), warm_start_basis=None)
+    assert r.status == "optimal" and r.objective == 10.0 and r.basis is not None
+
+
+def test_sequential_warm_starts_with_growing_capacity(gpu_engine_module):
+    """test_warm_start.py:359-390: the basis of each solve starts the next; the optimum does not move."""
+    basis, prev = None, None
+    for capacity in (100.0, 110.0, 120.0, 130.0):
+        r = nfs.solve_min_cost_flow(_problem([("s", 100.0), ("t", -100.0)], [("s", "t", capacity, 1.0)]), warm_start_basis=basis)
+        assert r.status == "optimal"
+        if prev is not None:
+            assert r.objective == prev
+        basis, prev = r.basis, r.objective
+
+
+def test_warm_start_that_needs_no_artificial_arc_logs_it(gpu_engine_module, caplog):
+    """test_warm_start.py:755-790 (the reference logs the Phase-1 skip; here: the basis is applied and the solve only
+    confirms optimality)."""
+    p = _problem([("s", 25.0), ("m", 0.0), ("t", -25.0)], [("s", "m", 30.0, 1.0), ("m", "t", 30.0, 1.0)])
+    r1 = nfs.solve_min_cost_flow(p)
+    with caplog.at_level(logging.INFO):
+        r2 = nfs.solve_min_cost_flow(p, warm_start_basis=r1.basis)
+    assert r2.status == "optimal" and r2.objective == r1.objective == 50.0 and r2.iterations <= r1.iterations
+    msgs = [rec.getMessage().lower() for rec in caplog.records]
+    assert msgs and any("warm" in m or "phase" in m for m in msgs)
 
 
 def test_sequential_warm_starts_with_increasing_demand(gpu_engine_module):
