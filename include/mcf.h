@@ -17,6 +17,12 @@
  *       simplex.py:528-617 ...................................................  mcf_price_once
  *   ProgressCallback cadence  simplex.py:1143-1154 ...........................  mcf_progress_cb
  *   UnboundedProblemError(entering_arc, reduced_cost)  exceptions.py:65-93 ...  MCF_ST_UNBOUNDED + stats.unbounded_arc
+ *   warm start  simplex.py:740-1010, 1491-1532 ..............................  mcf_set_basis
+ *   AdaptiveTuner.adapt_block_size  simplex_adaptive.py:98-151 and the
+ *       periodic Devex reset  simplex.py:1370-1400 ..........................  inside mcf_solve (MCF_RULE_DEVEX_BLOCK)
+ *   specialised pivot strategies  specialized_pivots.py:69-223, 452-527 .....  MCF_RULE_DANTZIG_FULL (row scan),
+ *                                                                               mcf_options.forward_first (min-cost scan)
+ *   parse_dimacs_file  benchmarks/parsers/dimacs.py:77-286 ..................  mcf_dimacs_scan / mcf_dimacs_load
  *
  * Conventions: plain pointers and sizes only; integer return codes (0 = ok, < 0 =
  * MCF_E_*), never exceptions; the caller owns every buffer it passes; the library owns

@@ -24,8 +24,8 @@ struct Emul {
     std::vector<int32_t> order1, path1, path2, pos1, psz1, ppos1, ppos2, reach, chg;
     std::vector<McfNode> rec1, rec2;
     std::vector<McfSeg> seg;
-    McfCtx ctx;
-    McfView view;
+    McfCtx ctx{};
+    McfView view{};    // value-initialised: every optional pointer of the view starts out null
     int rule = 0;
     int fwd_first = 0;          // bit 8 of the `rule` argument: forward candidates first (mcf_options.forward_first)
     int price_blocks = 8;
@@ -73,6 +73,8 @@ void bind(Emul& e) {
     v.ctx = &e.ctx;
     v.fwd_first = e.fwd_first;
     v.rc_partial = 0;
+    v.vkey = nullptr;   // (the compressed keys ride on the resident reduced costs, which the emulation does not keep)
+    v.vk_bigm = im.big_m; v.vk_half = 1 << 28; v.vk_pad = 0;
     v.rcache = nullptr;  // the emulation always prices by gathering potentials: an independent
     v.adj_off = nullptr; // check of the engine's resident reduced costs
     v.adj = nullptr;
