@@ -311,7 +311,8 @@ struct McfDirty {
 //   big-M < 2^29:   every violation is < 2^31 -> the code is the violation itself;
 //   otherwise:      level j = round(viol / big-M) in {0, 1, 2} and offset d = viol - j * big-M with |d| < half:
 //                   code = j * 2^29 + (d + 2^28)   (levels cannot overlap because big-M >= 2^29 > 2 * half);
-//   anything else:  MCF_VKEY_SAT (the sweep fetches the exact reduced cost for such an arc).
+//   anything else:  MCF_VKEY_SAT = "not coded" (NOT "larger than every code": a violation between two levels is
+//                   saturated too): the sweep fetches the exact reduced cost of such an arc and compares exact values.
 #define MCF_VKEY_SAT 0x7fffffff
 MCF_HD int32_t mcf_vkey(int64_t viol, int64_t bigm, int32_t half) {
     if (viol <= 0) return 0;
@@ -324,6 +325,13 @@ MCF_HD int32_t mcf_vkey(int64_t viol, int64_t bigm, int32_t half) {
     else return MCF_VKEY_SAT;
     if (d >= half || d <= -half) return MCF_VKEY_SAT;
     return (int32_t)(((int64_t)j << 29) + d + ((int64_t)1 << 28));
+}
+
+// the violation a (non-saturated, non-zero) code stands for
+MCF_HD int64_t mcf_vkey_decode(int32_t code, int64_t bigm, int32_t half) {
+    if (bigm < ((int64_t)1 << 29) && half >= (1 << 28)) return code;
+    const int64_t j = code >> 29, d = (int64_t)(code & ((1 << 29) - 1)) - ((int64_t)1 << 28);
+    return j * bigm + d;
 }
 
 // Dantzig key of an eligible arc: its violation; with fwd_first a forward arc (state > 0) carries bit 61 on top, so every

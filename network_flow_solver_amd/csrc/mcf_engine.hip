@@ -353,9 +353,11 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_v(McfView v, int64_t sh
     if (g0 < g_hi) load_batch(g0);   // before the control block is looked at: a full sweep's slice does not depend on it
     if (use_block == 2 && (c->minor_left > 0 || c->status != MCF_RUNNING)) return;   // candidate list still live
     if (INC && v.dirty && (c->status != MCF_RUNNING || !v.dirty->flag[blockIdx.x])) return;  // clean block: candidate stands
-    int32_t best = 0;      // best code of this lane
+    int32_t best = 0;      // best code of this lane (MCF_VKEY_SAT: its violation is not coded, best_x holds it)
     int64_t best_i = -1;   // its engine arc
-    int64_t best_x = 0;    // exact violation, kept only while best == MCF_VKEY_SAT
+    int64_t best_x = 0;    // exact violation while best == MCF_VKEY_SAT
+    const int64_t bigm = v.vk_bigm;
+    const int32_t half = v.vk_half;
     auto exact = [&](int64_t i) { return -(int64_t)v.state[i] * v.rcache[i]; };
     if (c->status == MCF_RUNNING) {
         if (INC && swept && threadIdx.x == 0) {
@@ -372,14 +374,17 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_v(McfView v, int64_t sh
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int32_t kk = ks[k];
-                    if (kk < best || kk == 0) continue;
+                    if (kk == 0 || (kk < best && best != MCF_VKEY_SAT)) continue;   // ineligible / cannot win
                     const int64_t i = (g << 2) + k;
                     if (i < lo || i >= hi) continue;
-                    if (kk > best) { best = kk; best_i = i; if (kk == MCF_VKEY_SAT) best_x = exact(i); }
-                    else if (kk == MCF_VKEY_SAT) {   // both beyond the code: exact comparison
-                        const int64_t xv = exact(i);
-                        if (xv > best_x || (xv == best_x && orig[i] < orig[best_i])) { best_x = xv; best_i = i; }
-                    } else if (orig[i] < orig[best_i]) best_i = i;   // equal codes = equal violations: lowest caller's index
+                    if (kk != MCF_VKEY_SAT && best != MCF_VKEY_SAT) {   // the common case: codes order like violations
+                        if (kk > best) { best = kk; best_i = i; }
+                        else if (orig[i] < orig[best_i]) best_i = i;    // equal codes = equal violations: lowest caller's index
+                    } else {                                             // an arc that is not coded is involved: exact values
+                        const int64_t xv = kk == MCF_VKEY_SAT ? exact(i) : mcf_vkey_decode(kk, bigm, half);
+                        const int64_t cur = best_i < 0 ? 0 : (best == MCF_VKEY_SAT ? best_x : mcf_vkey_decode(best, bigm, half));
+                        if (xv > cur || (xv == cur && best_i >= 0 && orig[i] < orig[best_i])) { best = kk; best_i = i; best_x = xv; }
+                    }
                 }
             }
             g0 += stride * U;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_v(McfView v, int64_t sh
     }
     int64_t key = 0, arc = -1;
     if (best_i >= 0) {
-        key = best == MCF_VKEY_SAT ? best_x : exact(best_i);
+        key = best == MCF_VKEY_SAT ? best_x : mcf_vkey_decode(best, bigm, half);   // the exact violation, as k_price_rc reports it
         arc = mcf_pack_arc(orig[best_i], best_i);
     }
     block_argmax<kPriceThreads>(key, arc);
