@@ -899,8 +899,15 @@ def test_dimacs_file_to_flat_problem_to_solve(gpu_engine_module, tmp_path, strat
         res = nfs.solve_min_cost_flow(prob, opts)
         exp = next(iter(case["expected"].values()))
         assert res.status == exp["status"] == "optimal" and res.objective == exp["objective"]
-        if strategies_agree_on(case):
+        ref = oracle.solve_dicts(case["nodes"], case["arcs"], case["directed"], case["tolerance"], "dantzig")
+        if ref.min_nonbasic_abs_rc > 1e-6:        # unique optimum (tiny_transportation has two flows of cost 111)
             assert res.flows == {(t, h): fl for t, h, fl in exp["flows"]}
+        else:
+            bal = {str(nd["id"]): float(nd.get("supply", 0.0)) for nd in case["nodes"]}
+            for (t, h), fl in res.flows.items():
+                bal[t] -= fl
+                bal[h] += fl
+            assert all(abs(v) <= 1e-9 for v in bal.values())
         assert isinstance(res.flows.array, np.ndarray) and len(res.duals) == prob.n   # flat views stay available
     entry, inst = load_synthetic()[3]                                # netgen_8_08a(synthetic)
     f = tmp_path / "netgen_8_08a.min"
@@ -925,11 +932,6 @@ def test_dimacs_file_to_flat_problem_to_solve(gpu_engine_module, tmp_path, strat
     assert a.status == b.status and a.objective == b.objective
     if a.status == "optimal":
         assert (a.flows.array >= lower).all()
-
-
-def strategies_agree_on(case) -> bool:
-    from conftest import strategies_agree
-    return strategies_agree(case)
 
 
 # ------------------------------------------------------------------ BASELINE.json sizes: solved to optimality
