@@ -13,14 +13,15 @@ Dantzig pricing kernel" -- as a seeded synthetic stand-in (the LEMON file is not
 offline).  That instance is 27 KB per sweep: it runs as ONE persistent LDS-resident workgroup
 (k_solve_small) and is latency-bound by construction, which is what its `roofline` object says.
 The same line therefore also carries
-  * ``hbm_point``: configs[4]'s shape (1 M nodes / 16 M arcs), where the pricing sweep (k_price_rc) is the dominant,
-    bandwidth-bound kernel -- its 151 MB working set still fits the 256 MiB Infinity Cache;
-  * ``hbm_point_beyond_infinity_cache``: 4 M nodes / 64 M arcs (604 MB per sweep), where the same kernel really
-    streams from HBM;
+  * ``hbm_point``: configs[4]'s shape (1 M nodes / 16 M arcs), where the pricing sweep (k_price_v) is the dominant,
+    bandwidth-bound kernel -- its 67 MB working set fits the 256 MiB Infinity Cache;
+  * ``hbm_point_beyond_infinity_cache``: 4 M nodes / 64 M arcs (268 MB of key codes per sweep), where the same
+    kernel really streams from HBM;
   * ``config_points``: the other single-GPU-runnable BASELINE.json configs with the engine's defaults.
 
 ``roofline`` always describes the kernel the timed region ran.  ``achieved`` = the kernel's own compulsory bytes per
-launch (9 B per arc for the resident-reduced-cost sweep, 13 B with Devex weights) / its launch
+launch (4 B per arc for the key-code sweep, 9 B for the resident-reduced-cost sweep, 13 B with
+Devex weights) / its launch
 duration measured with HIP events on the engine's stream; ``traffic`` = HBM-side bytes per launch from the committed
 rocprofv3 PMC passes (profiles/pmc_traffic.json).  SURVEY.md section 8d's per-arc figure for the gather formulation
 (13 B/arc + 8 B/node) is kept as ``survey_8d`` for comparison; it is not a physical rate of this kernel.
@@ -90,22 +91,26 @@ def run_pivots(eng, count: int) -> int:
     leg: the control block the solve leaves on the host answers stats() without another device round trip."""
     done = 0
     restarts = 0
+    _, before = eng.poll()                       # (the host copy of the control block: no device round trip)
     while done < count:
-        before = eng.stats()["pivots"]
         eng.solve(max_pivots=count - done)
-        st = eng.stats()
-        done += st["pivots"] - before
-        if st["status"] != "iteration_limit" and done < count:
+        status, now = eng.poll()
+        done += now - before
+        before = now
+        if status != 2 and done < count:         # not "iteration_limit": optimal (or infeasible) before the count was reached
             eng.reset()
             restarts += 1
+            before = 0
     return restarts
 
 
-def kernel_name(mode: int, rule: int, incremental: bool) -> str:
+def kernel_name(mode: int, rule: int, incremental: bool, bytes_per_arc: float = 9.0) -> str:
     if mode == 2:
         return "k_solve_small"
     if mode == 3:
         return "k_solve_mid"
+    if mode == 1 and rule != 1 and bytes_per_arc < 5:
+        return f"k_price_v<{'true' if incremental else 'false'}>"          # 4-byte key codes
     if mode == 1:
         return f"k_price_rc<{1 if rule == 1 else 0},false,{'true' if incremental else 'false'}>"
     return f"k_price<{1 if rule == 1 else 0},false>"
@@ -193,10 +198,10 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         sweep_ms = eng.time_pricing(reps=50)            # back-to-back launches, no events in between
         out["kernel_ms"] = {"price": price_ms, "pivot": pivot_ms, "apply": apply_ms, "price_back_to_back": sweep_ms}
         per_pass = (p1["arcs_priced"] - p0["arcs_priced"]) / launches     # arcs one launch prices
-        if mode == 1:   # resident reduced costs: 8 B rc + 1 B state (+ 4 B Devex weight) per arc, 16 B per workgroup candidate
-            nbytes = (13 if rule == 1 else 9) * per_pass
-        else:           # gather sweep: SURVEY 8d's own figure
-            nbytes = (17 if rule == 1 else 13) * per_pass + 8 * (inst.n + 1)
+        # the engine states the compulsory bytes of one launch of ITS sweep kernel (mcf_stats.price_bytes): 4 B per arc
+        # for the key-code sweep, 9 B (13 Devex) for the resident-reduced-cost sweep, SURVEY 8d's figure for the gather
+        nbytes = float(p1["price_bytes"])
+        kname = kernel_name(mode, rule, incremental, nbytes / max(per_pass, 1))
         achieved = nbytes / (price_ms * 1e-3) / 1e9
         traffic, src = pmc_traffic(workload, kname)
         survey = (17 if rule == 1 else 13) * per_pass + 8 * (inst.n + 1)
@@ -210,8 +215,9 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
             "achieved_back_to_back": nbytes / (sweep_ms * 1e-3) / 1e9,
             "working_set_fits_infinity_cache": bool(nbytes < 256 * 2 ** 20),
             "survey_8d": {"bytes_per_launch": int(survey), "ratio_to_kernel_bytes": survey / max(nbytes, 1),
-                          "note": "SURVEY 8d prices the gather formulation (13 B/arc + 8 B/node); the resident-reduced-cost "
-                                  "sweep moves 9 B/arc and leaves the rest to k_update -- not a physical rate of this kernel"},
+                          "note": "SURVEY 8d prices the gather formulation (13 B/arc + 8 B/node); the resident sweeps move "
+                                  "4 B/arc (key codes) or 9 B/arc (reduced cost + state) and leave the rest to k_update -- "
+                                  "not a physical rate of this kernel"},
             "note": "ms_per_launch: HIP events around every pricing launch of the same K pivots (profiled pass, eager "
                     "launches); back_to_back: 50 launches between two events",
         }

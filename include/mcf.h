@@ -103,7 +103,8 @@ typedef struct mcf_options {
                                 by its general pricing for what is left (simplex.py:1061-1064).  The row-scan rule it uses for
                                 transportation problems (specialized_pivots.py:69-117) IS MCF_RULE_DANTZIG_FULL. */
     int32_t compressed_keys; /* Dantzig / candidate-list grid sweeps over 4-byte key codes (one per arc, kept exact next to the resident
-                                reduced costs) instead of 8 B reduced cost + 1 B state: 0 = auto (on), -1 = off */
+                                reduced costs) instead of 8 B reduced cost + 1 B state: 0 = auto (full-sweep Dantzig handles from 4 M arcs on, where the
+                                sweep is bandwidth-bound and read whole), 1 = on, -1 = off */
     int32_t vkey_half_log2;  /* test hook: log2 of the half width of a code level (0 = 28); small values force the exact-compare path */
     int32_t reserved[1];     /* must be 0 */
 } mcf_options;
@@ -126,7 +127,8 @@ typedef struct mcf_stats {
     int64_t price_launches;
     int64_t pivot_launches;
     int64_t apply_launches;
-    int64_t price_bytes;      /* algorithmic bytes of one pricing launch: 13 B/arc + 8 B/node (17 for Devex) */
+    int64_t price_bytes;      /* compulsory bytes of one pricing launch of this handle's sweep kernel: 4 B/arc (k_price_v, key codes),
+                                 9 B/arc (k_price_rc; 13 Devex), or SURVEY 8d's 13 B/arc + 8 B/node (k_price gather; 17 Devex) */
     int64_t artificial_flow;  /* flow still on artificial arcs (> 0 at optimality = infeasible, simplex.py:1573-1624);
                                  -1 when mcf_get_result was asked for neither status, objective nor flow */
     int64_t pricing_mode;     /* 0 = gather sweep (k_price), 1 = resident reduced costs (k_price_rc + k_rcupd),

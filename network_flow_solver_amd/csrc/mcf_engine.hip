@@ -1290,7 +1290,12 @@ int upload_image(mcf_handle* h) {
     h->priced_per_pass = h->opt.rule == MCF_RULE_DEVEX_BLOCK ? h->shard_arcs * c.block_granules / MCF_GRANULES : h->shard_arcs;
     std::memset(&h->stats, 0, sizeof h->stats);
     h->stats.unbounded_arc = -1;
-    h->stats.price_bytes = (h->opt.rule == MCF_RULE_DEVEX_BLOCK ? 17 : 13) * h->priced_per_pass + 8 * (int64_t)im.n_nodes;
+    {   // compulsory bytes of ONE pricing launch of this handle's sweep kernel
+        const bool devex = h->opt.rule == MCF_RULE_DEVEX_BLOCK;
+        if (h->d_vkey && !devex) h->stats.price_bytes = 4 * h->priced_per_pass;                       // k_price_v: key codes
+        else if (h->rcached) h->stats.price_bytes = (devex ? 13 : 9) * h->priced_per_pass;            // k_price_rc: rc + state (+ weight)
+        else h->stats.price_bytes = (devex ? 17 : 13) * h->priced_per_pass + 8 * (int64_t)im.n_nodes; // k_price: SURVEY 8d's gather figure
+    }
     h->total_cap = 0;
     h->solved_once = false;
     h->ctx_current = true;  // *h_ctx was just copied to the device
@@ -1571,7 +1576,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         if ((e = dalloc(&h->d_psz1, NP)) != hipSuccess) return fail("hipMalloc psz", e);
         if ((e = hipMemset(h->d_psz0, 0, NP * 4)) != hipSuccess || (e = hipMemset(h->d_psz1, 0, NP * 4)) != hipSuccess) return fail("hipMemset psz", e);
         v.psz[0] = h->d_psz0; v.psz[1] = h->d_psz1;
-        if ((e = dalloc(&h->d_reach, NP / MCF_REACH_BLOCK + 1)) != hipSuccess) return fail("hipMalloc reach", e);
+        if ((e = dalloc(&h->d_reach, NP / MCF_REACH_BLOCK + 8)) != hipSuccess) return fail("hipMalloc reach", e);   // (+8: read four at a time)
+        if ((e = hipMemset(h->d_reach, 0, (NP / MCF_REACH_BLOCK + 8) * 4)) != hipSuccess) return fail("hipMemset reach", e);
         if ((e = dalloc(&h->d_chg, N)) != hipSuccess) return fail("hipMalloc chg", e);
         v.reach = h->d_reach; v.chg = h->d_chg;
     }
@@ -1623,7 +1629,13 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     v.vkey = nullptr;
     v.vk_bigm = im.big_m;
     v.vk_half = 1 << (opt.vkey_half_log2 > 0 && opt.vkey_half_log2 <= 28 ? opt.vkey_half_log2 : 28);
-    if (h->rcached && !h->mid && opt.rule != MCF_RULE_DEVEX_BLOCK && !opt.forward_first && opt.compressed_keys >= 0) {
+    // They pay where a sweep reads the whole shard and is bandwidth-bound: full (non-incremental) sweeps of the Dantzig rule
+    // from kIncrementalMinArcs arcs on (1 M / 16 M: sweep 24 -> 14 us).  Keeping the codes exact costs the reduced-cost patch a state
+    // byte and a 4-byte store per patched arc (k_update +1..3 us per pivot), which a candidate-list handle (one sweep per ~33
+    // pivots) or an incremental sweep (1 % of the arcs re-read per pivot) never earns back.  compressed_keys: 1 = on, -1 = off.
+    const bool keys_auto = opt.rule == MCF_RULE_DANTZIG_FULL && opt.full_sweeps > 0 && im.m >= kIncrementalMinArcs;
+    if (h->rcached && !h->mid && opt.rule != MCF_RULE_DEVEX_BLOCK && !opt.forward_first &&
+        (opt.compressed_keys > 0 || (opt.compressed_keys == 0 && keys_auto))) {
         if ((e = dalloc(&h->d_vkey, im.m_pad)) != hipSuccess) return fail("hipMalloc vkey", e);
         v.vkey = h->d_vkey;
     }

@@ -87,7 +87,7 @@ void bind(Emul& e) {
     v.psz[0] = im.psize.data();
     v.psz[1] = e.psz1.data();
     // coarse index over the sizes (see McfView::reach); the emulation keeps it exact
-    e.reach.assign(np / MCF_REACH_BLOCK + 1, 0);
+    e.reach.assign(np / MCF_REACH_BLOCK + 8, 0);
     e.chg.assign(im.n_nodes, 0);
     v.reach = e.reach.data();
     v.chg = e.chg.data();

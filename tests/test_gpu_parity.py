@@ -128,7 +128,7 @@ def test_compressed_pricing_keys(gpu_engine_module, rule, variant):
     assert (bigm >= 1 << 29) == (variant.startswith("levels"))
     kw = dict(rule=rule, fused=False, mid_loop=-1, full_sweeps=-1 if rule == 0 else 1)
     sat_seen = 0
-    with e.McfEngine(inst.n, inst.tail, inst.head, cost, inst.cap, inst.supply, vkey_half_log2=half_log2, **kw) as eng:
+    with e.McfEngine(inst.n, inst.tail, inst.head, cost, inst.cap, inst.supply, vkey_half_log2=half_log2, compressed_keys=1, **kw) as eng:
         for budget in (0, 1, 5, 40, 300, 10 ** 9):
             if budget:
                 eng.solve(max_pivots=budget)
