@@ -106,7 +106,8 @@ typedef struct mcf_options {
                                 reduced costs) instead of 8 B reduced cost + 1 B state: 0 = auto (full-sweep Dantzig handles from 4 M arcs on, where the
                                 sweep is bandwidth-bound and read whole), 1 = on, -1 = off */
     int32_t vkey_half_log2;  /* test hook: log2 of the half width of a code level (0 = 28); small values force the exact-compare path */
-    int32_t reserved[1];     /* must be 0 */
+    int32_t climb_depth;     /* cycle search: end points no deeper than this are climbed outright whatever cycle_scan says
+                                (0 = auto: 3 up to 32 768 nodes, 8 above; -1 = never) */
 } mcf_options;
 
 typedef struct mcf_stats {

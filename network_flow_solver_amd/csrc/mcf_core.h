@@ -227,7 +227,8 @@ struct McfCtx {
     // ---- cycle search: round trips the pointer-chasing climb may take before the position-space scan
     // takes over (only when the view carries psz[]); diagnostics
     int32_t climb_budget;
-    int32_t pad0;
+    int32_t climb_depth;       // end points no deeper than this are climbed outright (at most that many round trips: cheaper
+                               // than the scan's fixed passes while the tree is shallow, e.g. the first pivots of a cold start)
     int64_t scans;             // pivots whose cycle was completed by the scan
     int64_t scan_rounds;       // chunk iterations of those scans
 };
@@ -614,6 +615,14 @@ MCF_HD void mcf_cycle_init(const McfView& v, McfCycle* cy) {
     cy->d1 = MCF_INF; cy->d2 = MCF_INF;
     cy->k1 = -1; cy->k2 = -1;
     cy->n1 = 0; cy->n2 = 0;
+}
+
+// Round trips the pointer-chasing climb may take before the scan takes over: unlimited without position-space sizes
+// and for shallow end points (the climb then needs at most climb_depth trips), else the handle's budget.
+MCF_HD int32_t mcf_climb_budget(const McfView& v, const McfCycle& cy) {
+    if (!v.psz[0]) return INT32_MAX;
+    const int32_t deep = cy.ru.depth > cy.rw.depth ? cy.ru.depth : cy.rw.depth;
+    return deep <= v.ctx->climb_depth ? INT32_MAX : v.ctx->climb_budget;
 }
 
 // Returns false on an internal error (depths out of sync).  On return cy->u == cy->w means joined.
@@ -1069,7 +1078,7 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     McfCycle cy;
     mcf_cycle_init(v, &cy);
     MCF_PSTAMP(14);
-    if (!mcf_pivot_climb(v, &cy, v.psz[0] ? v.ctx->climb_budget : INT32_MAX)) return;
+    if (!mcf_pivot_climb(v, &cy, mcf_climb_budget(v, cy))) return;
     MCF_PSTAMP(15);
     if (cy.u != cy.w) {
         McfScanAcc acc;

@@ -418,11 +418,7 @@ constexpr int kMaxRcupdBlocks = 1024;
 // posbuf[cur^1], pi and the depths of T2; the update half writes rcache.  One launch boundary less per pivot.
 // `c` is the control block (kernel argument memory / LDS); the pass is spread over `stride` lanes of which this
 // one is `tid`, and over `ngroups` 16-lane groups of which this lane belongs to `group` (sub-lane `sub`).
-__device__ __forceinline__ int32_t wave_max32(int32_t x) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const int32_t y = __shfl_xor(x, o); x = y > x ? y : x; }
-    return x;
-}
+__device__ __forceinline__ int32_t wave_max32(int32_t x) { return (int32_t)mcf_wave_max64((int64_t)x); }  // DPP steps, no LDS crossbar
 
 // `tid` of `stride` lanes, both multiples of 64 apart: whole waves.  With a coarse index (v.reach) every wave takes
 // aligned blocks of 64 positions, so that it holds all 64 new subtree sizes of a block and re-indexes reach[] in the
@@ -553,7 +549,7 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
             MCF_PSTAMP(2);
             mcf_cycle_init(v, &S.cy);
             // sequential part: at most climb_budget dependent round trips
-            if (mcf_pivot_climb(v, &S.cy, v.psz[0] ? c->climb_budget : INT32_MAX)) go = S.cy.u == S.cy.w ? 1 : 2;
+            if (mcf_pivot_climb(v, &S.cy, mcf_climb_budget(v, S.cy))) go = S.cy.u == S.cy.w ? 1 : 2;
             if (go == 2) mcf_scan_init(&S.acc);
         }
         S.go = go;
@@ -1256,6 +1252,9 @@ int upload_image(mcf_handle* h) {
     }
     c.minor_cap = mcf_minor_cap(h->price_blocks);
     c.climb_budget = h->climb_budget;
+    // shallow end points are climbed outright: one round trip per level beats the scan's fixed passes up to ~3 levels at
+    // mid size (one plain round) and ~8 levels where the coarse index is used (two passes over up to 16 K words first)
+    c.climb_depth = h->opt.climb_depth > 0 ? h->opt.climb_depth : (h->opt.climb_depth < 0 ? 0 : (im.n_nodes > 32768 ? 8 : 3));
     *h->h_ctx = c;
     if (h->shards > 1 && !h->d_full_tab) {
         int32_t tab[MCF_NUM_BUCKETS * 2];

@@ -211,6 +211,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     c.max_pivots = max_pivots < 0 ? (20 * (m + n) > 100 ? 20 * (m + n) : 100) : max_pivots;
     init_blocks(e, block_size);
     c.climb_budget = climb_budget < 0 ? INT32_MAX : climb_budget;
+    c.climb_depth = 0;   // (the cycle search never changes the pivot sequence; the emulation scans whenever it is asked to)
     const auto t0 = std::chrono::steady_clock::now();
     int64_t ntrace = 0;
     while (c.status == MCF_RUNNING) {

@@ -163,7 +163,7 @@ def test_cycle_scan_equals_cycle_climb(gpu_engine_module, idx, rule):
     to the CPU emulation."""
     _, inst = load_synthetic()[idx]
     # (the LDS-resident loop always climbs: kernel-per-phase path here, the persistent loop has its own test)
-    runs = {cs: _solve(gpu_engine_module, inst, rule, cycle_scan=cs, fused=False, mid_loop=-1) for cs in (-1, 1, 4)}
+    runs = {cs: _solve(gpu_engine_module, inst, rule, cycle_scan=cs, climb_depth=-1, fused=False, mid_loop=-1) for cs in (-1, 1, 4)}
     r0, t0 = runs[-1]
     assert r0.stats["cycle_scans"] == 0 and (t0["psize"] == -1).all()      # sizes are not even kept
     em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, climb_budget=0)
@@ -415,7 +415,7 @@ def test_cycle_scan_with_cycles_longer_than_the_lds_buffers(gpu_engine_module, m
     inst = _chain_instance(12000)
     em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0, climb_budget=0)
     assert em["status"] == "optimal" and em["cycle_arcs"] / em["pivots"] > 4096
-    res, tree = _solve(gpu_engine_module, inst, 0, mid_loop=mid_loop)
+    res, tree = _solve(gpu_engine_module, inst, 0, mid_loop=mid_loop, climb_depth=-1)
     assert res.status == "optimal" and res.objective == em["objective"]
     assert res.stats["pivots"] == em["pivots"] and res.stats["cycle_arcs"] == em["cycle_arcs"]
     assert res.stats["cycle_scans"] == em["scans"]
