@@ -436,24 +436,45 @@ __device__ __forceinline__ void apply_pass(const McfView& v, const McfCtx& c, in
     const int64_t gw = tid >> 6, nw = stride >> 6;
     const int32_t B0 = lo >> MCF_REACH_SHIFT, B1 = hi > lo ? (hi - 1) >> MCF_REACH_SHIFT : B0 - 1;
     const int32_t P0 = plo >> MCF_REACH_SHIFT, P1 = phi > plo ? (phi - 1) >> MCF_REACH_SHIFT : P0 - 1;
-    auto block = [&](int32_t b, bool moved) {
-        const int32_t j = (b << MCF_REACH_SHIFT) + lane;
-        int32_t z = 0;
-        if (j < v.n_nodes) {
-            const bool in_cur = j >= lo && j < hi, in_prev = j >= plo && j < phi;
-            z = (moved && (in_cur || in_prev)) ? mcf_apply_one(v, c, j) : zsrc[j];
+    // Up to KB blocks of a wave are permuted first and re-indexed afterwards: the sizes a block's re-indexing needs are
+    // loaded by the permutation itself, and using them right away would make every block wait for its own loads
+    // (measured at 1 M nodes: k_update 8.6 -> 11.1 us); deferred, the loads of all KB blocks are in flight together.
+    constexpr int KB = 4;
+    auto blocks = [&](int64_t first, int64_t last, int64_t skip_lo, int64_t skip_hi) {
+        for (int64_t b0 = first + gw; b0 <= last; b0 += nw * KB) {
+            int32_t z[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int64_t b = b0 + k * nw;
+                z[k] = 0;
+                if (b > last || (b >= skip_lo && b <= skip_hi)) continue;   // (wave-uniform)
+                const int32_t j = ((int32_t)b << MCF_REACH_SHIFT) + lane;
+                if (j < v.n_nodes) {
+                    const bool in_cur = j >= lo && j < hi, in_prev = j >= plo && j < phi;
+                    z[k] = (in_cur || in_prev) ? mcf_apply_one(v, c, j) : zsrc[j];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int64_t b = b0 + k * nw;
+                if (b > last || (b >= skip_lo && b <= skip_hi)) continue;
+                const int32_t j = ((int32_t)b << MCF_REACH_SHIFT) + lane;
+                const int32_t m = wave_max32(j < v.n_nodes ? j + z[k] : 0);
+                if (lane == 0) v.reach[b] = m;
+            }
         }
-        const int32_t m = wave_max32(j < v.n_nodes ? j + z : 0);
-        if (lane == 0) v.reach[b] = m;
     };
-    for (int64_t b = B0 + gw; b <= B1; b += nw) block((int32_t)b, true);
-    for (int64_t b = P0 + gw; b <= P1; b += nw)
-        if (b < B0 || b > B1) block((int32_t)b, true);
-    // shrunken subtrees outside the moved range: their blocks from the stable view (the finish pass wrote the new
-    // sizes into both copies)
+    blocks(B0, B1, 1, 0);        // the moved range
+    blocks(P0, P1, B0, B1);      // the catch-up range, minus what the first call covered
+    // shrunken subtrees outside both ranges: their blocks from the stable view (the finish pass wrote the new sizes
+    // into both copies)
     for (int64_t t = gw; t < c.nchg; t += nw) {
         const int32_t b = v.chg[t] >> MCF_REACH_SHIFT;
-        if ((b < B0 || b > B1) && (b < P0 || b > P1)) block(b, false);
+        if ((b < B0 || b > B1) && (b < P0 || b > P1)) {
+            const int32_t j = (b << MCF_REACH_SHIFT) + lane;
+            const int32_t m = wave_max32(j < v.n_nodes ? j + zsrc[j] : 0);
+            if (lane == 0) v.reach[b] = m;
+        }
     }
 }
 
