@@ -15,7 +15,7 @@ offline).  That instance is 27 KB per sweep: it runs as ONE persistent LDS-resid
 The same line therefore also carries
   * ``hbm_point``: configs[4]'s shape (1 M nodes / 16 M arcs), where the pricing sweep (k_price_v) is the dominant,
     bandwidth-bound kernel -- its 67 MB working set fits the 256 MiB Infinity Cache;
-  * ``hbm_point_beyond_infinity_cache``: 4 M nodes / 64 M arcs (268 MB of key codes per sweep), where the same
+  * ``hbm_point_beyond_infinity_cache``: 6 M nodes / 96 M arcs (403 MB of key codes per sweep), where the same
     kernel really streams from HBM;
   * ``config_points``: the other single-GPU-runnable BASELINE.json configs with the engine's defaults.
 
@@ -59,7 +59,8 @@ WORKLOADS = {
     "netgen_8_18a": ("netgen", 262144, 2097152),
     "netgen_8_20a": ("netgen", 1 << 20, 8 << 20),
     "netgen_1m_16m": ("netgen", 1 << 20, 16 << 20),
-    "netgen_4m_64m": ("netgen", 4 << 20, 64 << 20),   # working set beyond the 256 MiB Infinity Cache
+    "netgen_4m_64m": ("netgen", 4 << 20, 64 << 20),
+    "netgen_6m_96m": ("netgen", 6 << 20, 96 << 20),   # 403 MB of key codes per sweep: beyond the 256 MiB Infinity Cache
 }
 RULE_NAMES = {0: "full-scan Dantzig", 1: "block-search Devex", 2: "candidate list"}
 MODE_NAMES = {0: "gather sweep", 1: "resident reduced costs", 2: "fused LDS loop", 3: "persistent single-workgroup loop"}
@@ -379,9 +380,9 @@ def main():
                         "arcs_priced_per_sec": m_["arcs_priced_per_sec"], "arcs_covered_per_sec": m_["arcs_covered_per_sec"],
                         "ms_per_step": m_["ms_per_step"], "steps": m_["pivots"], "engine_path": m_["pricing_mode"]})
         line["config_points"] = pts
-        # beyond the Infinity Cache: 64 M arcs = 604 MB of reduced costs + states per sweep
+        # beyond the Infinity Cache: 96 M arcs = 403 MB of key codes per sweep (906 MB of reduced costs + states)
         _instances.clear()
-        far = measure_single("netgen_4m_64m", 40, 8, rule)
+        far = measure_single("netgen_6m_96m", 40, 8, rule)
         line["hbm_point_beyond_infinity_cache"] = {
             "workload": far["workload"], "value": far["arcs_priced_per_sec"], "unit": "arcs/s",
             "pivots_per_sec": far["pivots_per_sec"], "ms_per_step": far["ms_per_step"], "steps": far["pivots"],

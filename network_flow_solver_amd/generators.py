@@ -215,6 +215,7 @@ def named_instance(name: str) -> ArcSoA:
         "goto_8_16a": lambda: goto_style(256, 256, seed=1, name="goto_8_16a(synthetic)"),
         "netgen_1m_16m": lambda: netgen_style(1 << 20, 16 << 20, seed=1, name="netgen_1M_16M(synthetic)"),
         "netgen_4m_64m": lambda: netgen_style(4 << 20, 64 << 20, seed=1, name="netgen_4M_64M(synthetic)"),
+        "netgen_6m_96m": lambda: netgen_style(6 << 20, 96 << 20, seed=1, name="netgen_6M_96M(synthetic)"),
     }
     if name not in table:
         raise KeyError(f"unknown instance '{name}'; known: {sorted(table)}")

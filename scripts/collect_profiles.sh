@@ -9,18 +9,18 @@ cd $R
 timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default exit=$?"
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-hbm-point > $O/bench_default_20steps.json 2> $O/bench_20.err; echo "bench 20 steps exit=$?"
 timeout -k 10 300 python bench.py --workload netgen_1m_16m --no-hbm-point > $O/bench_netgen_1m_16m.json 2> $O/bench_1m.err; echo "bench 1m exit=$?"
-timeout -k 10 500 python bench.py --workload netgen_4m_64m --steps 100 --warmup 10 --no-cpu-baseline --no-hbm-point > $O/bench_netgen_4m_64m.json 2> $O/bench_4m.err; echo "bench 4m exit=$?"
+timeout -k 10 500 python bench.py --workload netgen_6m_96m --steps 100 --warmup 10 --no-cpu-baseline --no-hbm-point > $O/bench_netgen_6m_96m.json 2> $O/bench_4m.err; echo "bench 4m exit=$?"
 cd /tmp && export TMPDIR=/tmp
-for tag in default netgen_1m_16m netgen_4m_64m; do
+for tag in default netgen_1m_16m netgen_6m_96m; do
   args="--no-cpu-baseline --no-hbm-point"
   [ $tag = netgen_1m_16m ] && args="$args --workload netgen_1m_16m"
-  [ $tag = netgen_4m_64m ] && args="$args --workload netgen_4m_64m --steps 100 --warmup 10"
+  [ $tag = netgen_6m_96m ] && args="$args --workload netgen_6m_96m --steps 100 --warmup 10"
   MCF_USE_GRAPH=0 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -o run -- python3 $R/bench.py $args > $O/prof_${tag}_bench.json 2> $O/prof_$tag.err
   echo "rocprof $tag exit=$?"
   f=$(find $O/prof_$tag -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$tag.csv
   rm -rf $O/prof_$tag
 done
-for wl in netgen_1m_16m netgen_4m_64m netgen_8_08a; do
+for wl in netgen_1m_16m netgen_6m_96m netgen_8_08a; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     out=$O/pmc_${wl}_$ctr
     rm -rf $out

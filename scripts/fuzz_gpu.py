@@ -28,9 +28,17 @@ while time.time() < t_end and runs < max_runs:
         w = rng.choice([6, 12, 20, 33, 50, 70, 110]); inst = generators.goto_style(w, w, seed=seed)
     rule = rng.choice([0, 1, 2])
     opts = dict(fused=rng.random() < 0.5, mid_loop=rng.choice([-1, 0, 1]), cycle_scan=rng.choice([-1, 0, 0, 1, 3]),
-                full_sweeps=rng.choice([-1, 0, 1]), use_graph=rng.random() < 0.7, batch_pivots=rng.choice([7, 32, 64]))
+                full_sweeps=rng.choice([-1, 0, 1]), use_graph=rng.random() < 0.7, batch_pivots=rng.choice([7, 32, 64]),
+                climb_depth=rng.choice([-1, 0, 0, 2, 9]),                                   # depth gate of the cycle search
+                compressed_keys=rng.choice([-1, 1, 1]), vkey_half_log2=rng.choice([0, 0, 9, 14]),   # key codes, narrow levels
+                forward_first=rule != 1 and rng.random() < 0.2)                              # assignment-style keys
+    cost = inst.cost * rng.choice([1, 1, 300])                                               # x300: big-M >= 2^29 (level coding)
+    if int(np.abs(cost).max()) * (inst.n + 2) >= 2 ** 43:
+        cost = inst.cost
+    inst.cost = cost
     cap = rng.choice([10 ** 9, 10 ** 9, 137, 2500])
-    em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, max_pivots=cap)
+    em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule | (0x100 if opts["forward_first"] else 0),
+                           max_pivots=cap)
     try:
         with engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, **opts) as eng:
             if rng.random() < 0.3 and cap > 200:          # budgeted prefix + resume
