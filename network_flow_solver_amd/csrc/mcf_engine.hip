@@ -1201,6 +1201,8 @@ struct mcf_handle {
     std::string err;
     bool solved_once = false;
     bool ctx_current = false;  // *h_ctx equals the device control block (no kernel was enqueued since it was read)
+    bool external_driver = false;  // the caller enqueues the pivots itself (mcf_enqueue_*), possibly by replaying a graph it
+                                   // captured: the library cannot know when the control block changes, so every read goes to the device
 };
 
 namespace {
@@ -1319,6 +1321,7 @@ int upload_image(mcf_handle* h) {
     h->total_cap = 0;
     h->solved_once = false;
     h->ctx_current = true;  // *h_ctx was just copied to the device
+    h->external_driver = false;
     return MCF_OK;
 }
 
@@ -1434,7 +1437,7 @@ int read_ctx(mcf_handle* h, hipStream_t s) {
     return MCF_OK;
 }
 // the host copy of the control block, refreshed only when something ran since it was last read
-int sync_ctx(mcf_handle* h, hipStream_t s) { return h->ctx_current ? MCF_OK : read_ctx(h, s); }
+int sync_ctx(mcf_handle* h, hipStream_t s) { return (h->ctx_current && !h->external_driver) ? MCF_OK : read_ctx(h, s); }
 
 void free_all(mcf_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
@@ -1713,6 +1716,7 @@ int mcf_set_max_pivots(mcf_handle* h, int64_t max_total_pivots) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total_cap = max_total_pivots;
     h->ctx_current = false;
+    h->external_driver = true;
     return MCF_OK;
 }
 
@@ -1730,6 +1734,7 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
     if (max_pivots < 0) max_pivots = 20 * (m + n) > 100 ? 20 * (m + n) : 100;  // simplex.py:1470
     int rc = sync_ctx(h, h->stream);
     if (rc) return rc;
+    h->external_driver = false;   // from here on the library enqueues the pivots itself
     const int64_t start = h->h_ctx->pivots;
     const int64_t final_cap = start + max_pivots;
     if (cb_interval <= 0) cb_interval = 100;
@@ -1930,6 +1935,7 @@ int mcf_enqueue_price(mcf_handle* h, void* stream, int64_t* cand_out_dev) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int32_t rule = h->opt.rule;
     h->ctx_current = false;
+    h->external_driver = true;
     launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG);
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kReduceThreads), 0, s, h->d_cand, h->price_blocks,
                        reinterpret_cast<McfCand*>(cand_out_dev));
@@ -1942,6 +1948,7 @@ int mcf_enqueue_pivot(mcf_handle* h, void* stream, const int64_t* cands_dev, int
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     h->ctx_current = false;
+    h->external_driver = true;
     launch_k_pivot(h, s, reinterpret_cast<const McfCand*>(cands_dev), ncand, h->opt.rule, 1);
     launch_apply(h, s);
     HIP_TRY(h, hipGetLastError());
@@ -1961,6 +1968,7 @@ int mcf_enqueue_price_list(mcf_handle* h, void* stream, int64_t* cands_out_dev) 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int32_t rule = h->opt.rule;
     h->ctx_current = false;
+    h->external_driver = true;
     // the pricing grid writes one candidate per workgroup straight into the caller's buffer (price_blocks entries);
     // candidate-list rule: a no-op while minor iterations are pending, so the buffer keeps the live list
     launch_price(h, s, h->view, rule, rule != MCF_RULE_DANTZIG, reinterpret_cast<McfCand*>(cands_out_dev));
@@ -1973,6 +1981,7 @@ int mcf_enqueue_pivots(mcf_handle* h, void* stream, const int64_t* cands_dev, in
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     h->ctx_current = false;
+    h->external_driver = true;
     for (int i = 0; i < count; ++i) {  // slot 0 takes the fresh list, the others re-price it (minor iterations)
         launch_k_pivot(h, s, reinterpret_cast<const McfCand*>(cands_dev), ncand, h->opt.rule, i == 0 ? 1 : 0);
         launch_apply(h, s);

@@ -205,6 +205,11 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
     workload = args.workload or "netgen_8_08a"
 
     strong = getattr(args, "scaling", "weak") == "strong"
+    verbose = os.environ.get("MCF_DIST_VERBOSE") == "1"
+
+    def note(msg: str) -> None:
+        if verbose:
+            os.write(2, f"[rank {rank}] {msg}\n".encode())
 
     def measure(wl: str, steps: int, warmup: int) -> dict:
         fam, n1, m1 = workloads[wl]
@@ -218,12 +223,16 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
             inst = generators.goto_style(n1 * scale, m1, seed=1, name=tag)
         else:
             inst = generators.netgen_style(n1 * scale, m1 * scale, seed=1, name=tag)
+        note(f"instance {inst.name} built")
         eng = HipShardEngine(inst, rule, rank, world, local_rank, full_sweeps=1)  # value counts every arc of every sweep: so price them all
+        note("engine created")
         force = os.environ.get("MCF_BENCH_FORCE_DIST") == "1"  # 1-GPU rehearsal: still issue the collective
         loop = PivotLoop(eng, dist, world, batch=32, always_gather=force,
                          use_graph=os.environ.get("MCF_DIST_GRAPH", "1") == "1",  # MCF_DIST_GRAPH=0: eager loop
                          listing=rule == 2)   # candidate list: one all-gather of the ranks' lists per minor_cap + 1 pivots
+        note(f"pivot loop ready ({'captured graph' if loop.graph is not None else 'eager'}; {loop.graph_error})")
         loop.run(warmup)
+        note("warm-up done")
         _, p0 = eng.poll()
         a0 = eng.eng.stats()["arcs_priced"]
         dist.barrier()
@@ -236,6 +245,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        note("timed region done")
         pivots = p1 - p0
         arcs = eng.eng.stats()["arcs_priced"] - a0          # whole-job accounting: every pass counts the arcs of ALL shards
         sweep_ms = eng.eng.time_pricing(reps=20)

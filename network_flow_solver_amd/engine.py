@@ -182,7 +182,7 @@ class McfEngine:
         opt.rule = rule
         opt.block_size = int(block_size or 0)
         opt.batch_pivots = int(batch_pivots)
-        # MCF_USE_GRAPH=0: eager launches (rocprofv3 on this image faults inside hipGraphLaunch for some graphs)
+        # MCF_USE_GRAPH=0: eager launches instead of captured graphs (the configuration the rocprofv3 summaries are taken in)
         opt.use_graph = 1 if use_graph and os.environ.get("MCF_USE_GRAPH", "1") != "0" else 0
         opt.profile = 1 if profile else 0
         opt.price_blocks = int(price_blocks)

@@ -32,4 +32,9 @@ for wl in netgen_1m_16m netgen_6m_96m netgen_8_08a; do
 done
 cd $R
 timeout -k 10 500 python scripts/solve_times.py > $O/solve_times.out 2>&1; echo "solve_times exit=$?"; cp gpurun_out/solve_times.json $O/solve_times.json
+(cd $R/network_flow_solver_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMCF_STAMPS -o $R/scripts/libmcf_stamps.so mcf_engine.hip) && {
+  timeout -k 10 200 python scripts/stamps_pivot.py > $O/stamps_pivot.txt 2>&1; echo "stamps pivot exit=$?"
+  timeout -k 10 100 python scripts/stamps_small.py > $O/stamps_small.txt 2>&1; echo "stamps small exit=$?"
+}
+timeout -k 10 400 python scripts/late_phase_profile.py netgen_1m_16m 2 0 1000000 2000000 3000000 > $O/late_phase_netgen_1m_16m.txt 2>&1; echo "late phase exit=$?"
 ls -la $O

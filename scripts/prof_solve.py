@@ -12,7 +12,7 @@ cap = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000_000
 cs = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 inst = generators.named_instance(name)
 with engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, cycle_scan=cs,
-                      use_graph=os.environ.get("MCF_USE_GRAPH", "1") != "0") as eng:  # (rocprofv3 needs MCF_USE_GRAPH=0: it faults inside hipGraphLaunch on this image)
+                      use_graph=os.environ.get("MCF_USE_GRAPH", "1") != "0") as eng:  # (profiles are taken with MCF_USE_GRAPH=0: eager launches, per-kernel durations unchanged)
     t0 = time.perf_counter()
     eng.solve(max_pivots=cap)
     dt = time.perf_counter() - t0
