@@ -1,14 +1,15 @@
-#!/bin/bash
-# Two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over scripts/pmc_sweep.py; summary under gpurun_out/pmc_r01g.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/final
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  out=$R/gpurun_out/pmc_$ctr
-  rm -rf $out
-  MCF_USE_GRAPH=0 PIVOTS=64 REPS=10 timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 $R/scripts/pmc_sweep.py > $R/gpurun_out/pmc_$ctr.log 2>&1
-  echo "$ctr exit=$?"; tail -1 $R/gpurun_out/pmc_$ctr.log
+for wl in netgen_1m_16m netgen_6m_96m; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    out=$O/pmc_${wl}_$ctr
+    rm -rf $out
+    MCF_USE_GRAPH=0 WL=$wl PIVOTS=64 REPS=10 timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 $R/scripts/pmc_sweep.py > $O/pmc_${wl}_$ctr.log 2>&1
+    echo "pmc $wl $ctr exit=$?"; tail -1 $O/pmc_${wl}_$ctr.log
+  done
+  (cd $R && python scripts/pmc_summarize.py $O/pmc_${wl}_FETCH_SIZE $O/pmc_${wl}_WRITE_SIZE > $O/pmc_$wl.txt)
+  rm -rf $O/pmc_${wl}_FETCH_SIZE $O/pmc_${wl}_WRITE_SIZE
+  grep "k_price_v" $O/pmc_$wl.txt | cut -c60-250
 done
-cd $R
-python scripts/pmc_summarize.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_r01g.txt
-cat gpurun_out/pmc_r01g.txt
-find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name '*.csv' -size +200k -delete
