@@ -20,12 +20,12 @@ while time.time() < t_end and runs < max_runs:
     rng = random.Random(seed)
     fam = rng.choice(["netgen", "gridgen", "goto"])
     if fam == "netgen":
-        n = rng.choice([40, 130, 300, 700, 1500, 3000, 6000, 12000, 20000])
+        n = rng.choice([40, 130, 300, 700, 1500, 3000, 6000, 12000, 20000, 45000, 90000])   # (> 32 768 positions: coarse index)
         inst = generators.netgen_style(n, n * rng.choice([4, 8, 12]), seed=seed)
     elif fam == "gridgen":
         w = rng.choice([6, 12, 20, 33, 50, 70, 110]); inst = generators.gridgen_style(w, rng.choice([w, w + 3]), seed=seed)
     else:
-        w = rng.choice([6, 12, 20, 33, 50, 70, 110]); inst = generators.goto_style(w, w, seed=seed)
+        w = rng.choice([6, 12, 20, 33, 50, 70, 110, 200]); inst = generators.goto_style(w, w, seed=seed)
     rule = rng.choice([0, 1, 2])
     opts = dict(fused=rng.random() < 0.5, mid_loop=rng.choice([-1, 0, 1]), cycle_scan=rng.choice([-1, 0, 0, 1, 3]),
                 full_sweeps=rng.choice([-1, 0, 1]), use_graph=rng.random() < 0.7, batch_pivots=rng.choice([7, 32, 64]),
@@ -37,6 +37,8 @@ while time.time() < t_end and runs < max_runs:
         cost = inst.cost
     inst.cost = cost
     cap = rng.choice([10 ** 9, 10 ** 9, 137, 2500])
+    if inst.n > 30000:
+        cap = rng.choice([2500, 12000, 40000])   # (a full emulated solve takes minutes at this size)
     em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule | (0x100 if opts["forward_first"] else 0),
                            max_pivots=cap)
     try:
