@@ -326,7 +326,9 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
 // (MCF_VKEY_SAT) is compared by its exact value, fetched on the spot.  The workgroup's candidate carries the exact
 // violation (one look-up per lane at the end, together with the caller's arc id), so k_pivot / k_reduce see what
 // they always saw.
-template <bool INC>
+// NT: the code stream is loaded with the non-temporal hint -- for sweeps larger than the Infinity Cache, where no line
+// is ever re-used before it is evicted (below that size the next sweep re-reads the lines from the cache: no hint).
+template <bool INC, bool NT = false>
 __global__ __launch_bounds__(kPriceThreads) void k_price_v(McfView v, int64_t shard, int64_t shards, int use_block,
                                                             McfCand* __restrict__ cand, int64_t* __restrict__ swept,
                                                             const int32_t* __restrict__ blk_tab) {
@@ -346,7 +348,12 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_v(McfView v, int64_t sh
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t g = g0 + u * stride;
-            q[u] = g < g_hi ? vk4[g] : make_int4(0, 0, 0, 0);
+            if (g >= g_hi) q[u] = make_int4(0, 0, 0, 0);
+            else if (NT) {
+                typedef int nt_int4 __attribute__((ext_vector_type(4)));
+                const nt_int4 w = __builtin_nontemporal_load(reinterpret_cast<const nt_int4*>(vk4) + g);
+                q[u] = make_int4(w.x, w.y, w.z, w.w);
+            } else q[u] = vk4[g];
         }
     };
     int64_t g0 = g_lo + lb * kPriceThreads + threadIdx.x;
@@ -1163,6 +1170,7 @@ struct mcf_handle {
     McfNode *d_rec1 = nullptr, *d_rec2 = nullptr;
     int64_t *d_rcache = nullptr, *d_adj_off = nullptr, *d_adj = nullptr;
     int32_t* d_vkey = nullptr;   // compressed Dantzig keys (4 B per arc), see McfView::vkey
+    bool nt_sweep = false;       // the key-code sweep is larger than the Infinity Cache: non-temporal loads
     int32_t *d_pos0 = nullptr, *d_pos1 = nullptr, *d_psz0 = nullptr, *d_psz1 = nullptr;
     int32_t *d_reach = nullptr, *d_chg = nullptr;  // coarse index over the position-space sizes + its scratch
     McfDirty* d_dirty = nullptr;
@@ -1333,7 +1341,9 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
     // use_block: 0 = whole shard, 1 = current Devex block, 2 = whole shard unless minor iterations are pending
     if (rule == MCF_RULE_CANDIDATE_LIST && use_block) use_block = 2;
     if (h->rcached && v.vkey && rule != MCF_RULE_DEVEX_BLOCK) {
+        const bool nt = h->nt_sweep;
         if (v.dirty) hipLaunchKernelGGL((k_price_v<true>), grid, block, 0, s, v, h->shard, h->shards, use_block, out, swept, (const int32_t*)h->d_full_tab);
+        else if (nt) hipLaunchKernelGGL((k_price_v<false, true>), grid, block, 0, s, v, h->shard, h->shards, use_block, out, swept, (const int32_t*)h->d_full_tab);
         else hipLaunchKernelGGL((k_price_v<false>), grid, block, 0, s, v, h->shard, h->shards, use_block, out, swept, (const int32_t*)h->d_full_tab);
     } else if (h->rcached) {
         if (rule == MCF_RULE_DEVEX_BLOCK)
@@ -1661,6 +1671,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         (opt.compressed_keys > 0 || (opt.compressed_keys == 0 && keys_auto))) {
         if ((e = dalloc(&h->d_vkey, im.m_pad)) != hipSuccess) return fail("hipMalloc vkey", e);
         v.vkey = h->d_vkey;
+        const char* nt_env = std::getenv("MCF_NT_SWEEP");   // A/B switch: 0 / 1 force, unset = by size
+        h->nt_sweep = nt_env ? nt_env[0] == '1' : (im.m_pad / (h->shards > 0 ? h->shards : 1)) * 4 > (int64_t)200 * 1024 * 1024;
     }
     // incremental pricing for the rules whose sweeps cover the whole shard (Dantzig, candidate list); not for the
     // persistent loop, whose instances are far too small for it (its kernel compiles the marking away)

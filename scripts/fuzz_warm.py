@@ -51,5 +51,7 @@ while time.time() < t_end:
         print("MISMATCH", json.dumps({"seed": seed, "family": fam, "n": inst.n, "rule": rule, "opts": opts, "kind": kind, "applied": bool(ok_basis),
                                       "status": [r.status, ref["status"]], "objective": [int(r.objective), int(ref["objective"])]}), flush=True)
     seed += 1
+    if runs % 50 == 0:
+        print(f"  ... {runs} runs, {fails} mismatches", flush=True)
 print(json.dumps({"runs": runs, "fails": fails, "basis_applied": applied, "fewer_pivots_than_cold": fewer}))
 sys.exit(1 if fails else 0)
