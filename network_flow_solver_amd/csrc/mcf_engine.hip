@@ -7,19 +7,23 @@
 //   k_solve_mid     <= 8 192 nodes: one persistent workgroup over global (L2-resident) state -- prices a Devex
 //                   block / re-prices the candidate list / sweeps a small arc list, pivots, permutes, patches.
 //   otherwise three kernels per pivot on one stream, 64 pivots per captured hipGraph:
-//     k_price_rc    grid-wide stream over RESIDENT reduced costs (8 B rc + 1 B state per arc, +4 B Devex weight):
-//                   per-lane best, DPP wave max, one candidate per workgroup.  HBM-bound at scale.  Incremental
-//                   from 4 M arcs: workgroups whose arcs did not change keep their candidate.
+//     k_price_v     Dantzig sweep over 4-BYTE KEY CODES (one per arc, ordering like the violation -state * rc): HBM-bound at
+//                   scale, 13.7 us for 16 M arcs; full-sweep Dantzig handles from 4 M arcs on.
+//     k_price_rc    the same sweep over RESIDENT reduced costs (8 B rc + 1 B state per arc, +4 B Devex weight):
+//                   per-lane best, DPP wave max, one candidate per workgroup.  Devex: the block comes from a granule
+//                   table and moves / resizes under the reference's tuner.  Incremental from 4 M arcs: workgroups
+//                   whose arcs did not change keep their candidate.
 //                   (k_price: the same sweep by gathering pi[tail], pi[head]; mode 0 / parity hook.)
-//                   Replaces simplex.py:498-617 and simplex_pricing.py:97-137, 310-357, 375-542.
+//                   Replaces simplex.py:498-617, simplex_pricing.py:97-137, 310-357, 375-542, simplex_adaptive.py:98-151.
 //     k_pivot       one workgroup of 1024: final arg-max over the workgroup candidates (or the candidates
 //                   all-gathered from the other ranks), cycle by a workgroup-wide scan over preorder positions
-//                   (mcf_pivot_scan; climb above 2^20 nodes), ratio test, then mcf_pivot_finish on all lanes (flow
-//                   update, stem re-parenting, segment table).  Replaces basis.py:178-241, simplex.py:1198-1425.
+//                   (mcf_pivot_scan; through the coarse index `reach` on large trees; shallow end points are climbed),
+//                   ratio test, then mcf_pivot_finish on all lanes (flow update, stem re-parenting, segment table).
+//                   Replaces basis.py:178-241, simplex.py:1198-1425.
 //     k_update      grid-wide block permutation of the preorder array + potential shift (pi += sigma) + position /
-//                   size rewrite, and -- in other workgroups of the same launch -- the patch of the resident
-//                   reduced costs of the arcs incident to the re-hung subtree.  Replaces the per-pivot BFS
-//                   rebuild (basis.py:82-122) and _update_tree_sets (simplex.py:1103-1107).
+//                   size rewrite + re-indexing of the coarse index, and -- in other workgroups of the same launch --
+//                   the patch of the resident reduced costs / key codes of the arcs incident to the re-hung subtree.
+//                   Replaces the per-pivot BFS rebuild (basis.py:82-122) and _update_tree_sets (simplex.py:1103-1107).
 //
 // The host enqueues `batch_pivots` pivots (optionally as one captured hipGraph), then
 // reads the small control block back once.  Kernels of a finished solve early-exit.

@@ -36,5 +36,5 @@ timeout -k 10 500 python scripts/solve_times.py > $O/solve_times.out 2>&1; echo 
   timeout -k 10 200 python scripts/stamps_pivot.py > $O/stamps_pivot.txt 2>&1; echo "stamps pivot exit=$?"
   timeout -k 10 100 python scripts/stamps_small.py > $O/stamps_small.txt 2>&1; echo "stamps small exit=$?"
 }
-timeout -k 10 400 python scripts/late_phase_profile.py netgen_1m_16m 2 0 1000000 2000000 3000000 > $O/late_phase_netgen_1m_16m.txt 2>&1; echo "late phase exit=$?"
+timeout -k 10 600 python scripts/late_phase_profile.py netgen_1m_16m 2 250000 > $O/late_phase_netgen_1m_16m.txt 2>&1; echo "late phase exit=$?"
 ls -la $O
