@@ -4,7 +4,7 @@
 //
 //   k_solve_small   whole instance in LDS: one persistent workgroup prices, pivots (two lanes climb the cycle in
 //                   lock step) and updates until the solve ends.
-//   k_solve_mid     <= 8 192 nodes: one persistent workgroup over global (L2-resident) state -- prices a Devex
+//   k_solve_mid     <= 1 536 nodes: one persistent workgroup over global (L2-resident) state -- prices a Devex
 //                   block / re-prices the candidate list / sweeps a small arc list, pivots, permutes, patches.
 //   otherwise three kernels per pivot on one stream, 64 pivots per captured hipGraph:
 //     k_price_v     Dantzig sweep over 4-BYTE KEY CODES (one per arc, ordering like the violation -state * rc): HBM-bound at
@@ -50,7 +50,9 @@ namespace {
 constexpr int kPriceThreads = 256;
 constexpr int kPivotThreads = 1024;  // one workgroup: final arg-max, cycle search (climb by one lane / scan by all), finish
 constexpr int kReduceThreads = 256;
-constexpr int kMidMaxNodes = 1 << 13;        // persistent single-workgroup loop (k_solve_mid): auto up to this many nodes ...
+constexpr int kMidMaxNodes = 1536;           // persistent single-workgroup loop (k_solve_mid): auto up to this many nodes (measured crossover
+                                             // with the kernel-per-phase graph: +12..21 % at 512 / 1 024 nodes, even at 2 048, -25 % at 4 096;
+                                             // profiles/r02_ab_engine_modes.txt) ...
 constexpr int kMidMaxArcsPerPivot = MCF_TUNER_MAX_ARCS + 1024;  // ... and this many arcs priced inside the loop per pivot
 constexpr int64_t kIncrementalMinArcs = (int64_t)1 << 22;  // incremental sweeps by default from this many arcs
 constexpr int kScanMaxNodes = 1 << 27;  // (with the coarse index the scan's cost no longer grows with the tree: no practical limit)
@@ -1659,7 +1661,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         } else if (opt.rule == MCF_RULE_DANTZIG_FULL) {
             per_pivot_arcs = im.m;
         }
-        const bool fits = im.n_nodes <= kMidMaxNodes && per_pivot_arcs <= kMidMaxArcsPerPivot;
+        // (the candidate list never gains from the loop -- its full sweeps run on the grid either way -- and stays on the graph)
+        const bool fits = im.n_nodes <= kMidMaxNodes && per_pivot_arcs <= kMidMaxArcsPerPivot && opt.rule != MCF_RULE_CANDIDATE_LIST;
         h->mid = h->rcached && scan_ok && h->shards == 1 && !opt.profile && opt.mid_loop >= 0 && (fits || opt.mid_loop > 0);
     }
     // compressed Dantzig keys for the grid sweeps of the Dantzig / candidate-list rules (4 B per arc instead of 9)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Time-to-optimal of a BASELINE-size instance with progress lines (a silent GPU command is killed after 7 minutes).
-    python scripts/solve_big.py netgen_1m_16m 2 [max_seconds]"""
+    python scripts/solve_big.py netgen_1m_16m 2 [max_seconds]      (MCF_SOLVE_OPTS='{"resident_rc": false}' passes engine options)"""
+import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -17,7 +19,9 @@ t0 = time.time()
 inst = generators.named_instance(name)
 print(f"{name}: generated in {time.time() - t0:.1f}s", flush=True)
 t0 = time.time()
-eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
+opts = json.loads(os.environ.get("MCF_SOLVE_OPTS", "{}"))
+eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, **opts)
+print(f"options {opts} -> pricing mode {eng.stats()['pricing_mode']}", flush=True)
 print(f"create {time.time() - t0:.1f}s", flush=True)
 t0 = time.time()
 last = [t0]
