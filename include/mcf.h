@@ -108,6 +108,10 @@ typedef struct mcf_options {
     int32_t vkey_half_log2;  /* test hook: log2 of the half width of a code level (0 = 28); small values force the exact-compare path */
     int32_t climb_depth;     /* cycle search: end points no deeper than this are climbed outright whatever cycle_scan says
                                 (0 = auto: 3 up to 32 768 nodes, 8 above; -1 = never) */
+    int32_t overlap_update;  /* captured graphs in which the pricing of pivot t+1 runs beside the tree permutation of pivot t (it needs
+                                only the reduced-cost half of the update): 1 = on, 0 / -1 = off.  Same pivot sequence.  Measured
+                                slower at every size (two cross-queue edges per pivot cost ~12 us on this stack;
+                                profiles/r02_ab_overlapped_graph.txt), so auto never picks it: kept as an A/B switch. */
 } mcf_options;
 
 typedef struct mcf_stats {

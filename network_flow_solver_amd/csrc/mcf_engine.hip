@@ -828,6 +828,16 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
 #endif
 }
 
+// The reduced-cost half alone (overlapped graphs: the next pivot's pricing waits for this half only, see build_graph)
+template <bool MARK>
+__global__ __launch_bounds__(kRcupdThreads) void k_rcupd(McfView g) {
+    McfView v = g;
+    if (!MARK) v.dirty = nullptr;
+    const McfCtx c = *v.ctx;
+    if (!c.apply) return;
+    rcupd_pass(v, c, (int64_t)blockIdx.x * (kRcupdThreads / 16) + (threadIdx.x >> 4), (int64_t)gridDim.x * (kRcupdThreads / 16), threadIdx.x & 15);
+}
+
 // ------------------------------------------------------------------ k_apply
 __global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
     const McfCtx c = *v.ctx;  // uniform: scalar loads
@@ -1206,6 +1216,10 @@ struct mcf_handle {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_batch = 0;
+    // overlapped graphs: pricing of pivot t+1 runs beside the tree permutation of pivot t (needs only the reduced-cost half)
+    bool overlap = false;
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> fork_ev;   // two per slot: pivot done (main -> side), priced (side -> main)
     // profiling events
     std::vector<hipEvent_t> events;
     hipEvent_t loop_ev[2] = {nullptr, nullptr};  // around every launch of a persistent pivot loop
@@ -1406,8 +1420,36 @@ int build_graph(mcf_handle* h, int batch) {
     if (h->graph_exec && h->graph_batch == batch) return MCF_OK;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    if (h->overlap) {
+        while (h->fork_ev.size() < (size_t)batch * 2) {
+            hipEvent_t e;
+            HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->fork_ev.push_back(e);
+        }
+    }
     HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream, i);
+    if (!h->overlap) {
+        for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream, i);
+    } else {
+        // main:  [price 0] pivot t -> permutation t ------------------------> pivot t+1 ...
+        // side:            \-> reduced-cost patch t -> price t+1 ---------/
+        // k_price reads what k_pivot and the patch wrote (control block, states, weights, reduced costs / key codes, dirty
+        // flags); the permutation writes order / pos / psz / pi / reach only, which pricing from resident values never reads.
+        const int32_t rule = h->opt.rule;
+        launch_price(h, h->stream, h->view, rule, rule != MCF_RULE_DANTZIG);
+        for (int i = 0; i < batch; ++i) {
+            hipEvent_t pivoted = h->fork_ev[(size_t)i * 2], priced = h->fork_ev[(size_t)i * 2 + 1];
+            launch_k_pivot(h, h->stream, h->d_cand, h->price_blocks, rule, 1);
+            HIP_TRY(h, hipEventRecord(pivoted, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->side, pivoted, 0));
+            if (h->view.dirty) hipLaunchKernelGGL(k_rcupd<true>, dim3(h->rcupd_blocks), dim3(kRcupdThreads), 0, h->side, h->view);
+            else hipLaunchKernelGGL(k_rcupd<false>, dim3(h->rcupd_blocks), dim3(kRcupdThreads), 0, h->side, h->view);
+            if (i + 1 < batch) launch_price(h, h->side, h->view, rule, rule != MCF_RULE_DANTZIG);
+            HIP_TRY(h, hipEventRecord(priced, h->side));
+            hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, h->stream, h->view);
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, priced, 0));
+        }
+    }
     HIP_TRY(h, hipStreamEndCapture(h->stream, &h->graph));
     HIP_TRY(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
     h->graph_batch = batch;
@@ -1459,6 +1501,8 @@ void free_all(mcf_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->fork_ev) (void)hipEventDestroy(e);
+    if (h->side) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : h->loop_ev) if (e) (void)hipEventDestroy(e);
     (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
@@ -1664,6 +1708,14 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         // (the candidate list never gains from the loop -- its full sweeps run on the grid either way -- and stays on the graph)
         const bool fits = im.n_nodes <= kMidMaxNodes && per_pivot_arcs <= kMidMaxArcsPerPivot && opt.rule != MCF_RULE_CANDIDATE_LIST;
         h->mid = h->rcached && scan_ok && h->shards == 1 && !opt.profile && opt.mid_loop >= 0 && (fits || opt.mid_loop > 0);
+    }
+    // overlapped graphs (build_graph), on request only: the idea -- on large trees the permutation outlasts the reduced-cost
+    // patch, so the next pricing could hide beside it -- loses to the cost of the two cross-queue edges per pivot
+    // (netgen_8_14a 55 K -> 33 K pivots/s, 1 M / 16 M 26 K -> 22 K; profiles/r02_ab_overlapped_graph.txt)
+    {
+        const bool able = h->rcached && !h->small && !h->mid && h->shards == 1 && !opt.profile && opt.rule != MCF_RULE_CANDIDATE_LIST;
+        h->overlap = able && opt.overlap_update > 0;
+        if (h->overlap && (e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     }
     // compressed Dantzig keys for the grid sweeps of the Dantzig / candidate-list rules (4 B per arc instead of 9)
     v.vkey = nullptr;

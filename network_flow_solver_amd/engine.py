@@ -55,6 +55,7 @@ class McfOptions(ctypes.Structure):
         ("cycle_scan", ctypes.c_int32), ("mid_loop", ctypes.c_int32), ("full_sweeps", ctypes.c_int32),
         ("devex_tuner", ctypes.c_int32), ("devex_stay", ctypes.c_int32), ("forward_first", ctypes.c_int32),
         ("compressed_keys", ctypes.c_int32), ("vkey_half_log2", ctypes.c_int32), ("climb_depth", ctypes.c_int32),
+        ("overlap_update", ctypes.c_int32),
     ]
 
 
@@ -159,7 +160,7 @@ class McfEngine:
                  shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
                  resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0, full_sweeps: int = 0,
                  devex_tuner: int = 0, devex_stay: bool = False, forward_first: bool = False, compressed_keys: int = 0,
-                 vkey_half_log2: int = 0, climb_depth: int = 0):
+                 vkey_half_log2: int = 0, climb_depth: int = 0, overlap_update: int = 0):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -196,6 +197,7 @@ class McfEngine:
         opt.forward_first = 1 if forward_first else 0
         opt.compressed_keys = int(compressed_keys)   # 0 auto (on for the Dantzig-key grid sweeps), -1 off
         opt.vkey_half_log2 = int(vkey_half_log2)
+        opt.overlap_update = int(overlap_update)     # 1 = pricing of pivot t+1 beside the permutation of pivot t (A/B switch: measured slower)
         opt.climb_depth = int(climb_depth)           # 0 auto, -1 never, k: end points of depth <= k are climbed outright
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])

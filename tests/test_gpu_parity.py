@@ -195,6 +195,34 @@ def test_cycle_scan_on_a_deep_tree(gpu_engine_module):
         check_tree_invariants(inst.n, t["parent"], t["size"], t["pos"], t["order"], t["depth"], t["psize"])
 
 
+@pytest.mark.parametrize("rule", [0, 1], ids=["dantzig", "devex_block"])
+@pytest.mark.parametrize("name,extra", [("netgen_8_12a", {}), ("gridgen_8_14a", {}), ("goto_8_14a", {"full_sweeps": -1}),
+                                        ("netgen_8_14a", {"compressed_keys": 1, "full_sweeps": 1})],
+                         ids=["netgen_8_12a", "gridgen_8_14a", "goto_8_14a_incremental", "netgen_8_14a_key_codes"])
+def test_overlapped_graph_equals_sequential_graph(gpu_engine_module, name, extra, rule):
+    """Captured graphs in which the pricing of pivot t+1 runs on a second stream beside the tree permutation of pivot t
+    (it waits for the reduced-cost patch only): same pivots, flows, tree, reduced costs as the one-stream graph, also
+    across budgets that end in the middle of a graph."""
+    inst = generators.named_instance(name)
+    e = gpu_engine_module
+    kw = dict(rule=rule, fused=False, mid_loop=-1, **extra)
+    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, overlap_update=1, **kw) as eng:
+        for budget in (1, 17, 1000):
+            eng.solve(max_pivots=budget)
+        assert eng.stats()["pivots"] == 1018 and eng.stats()["status"] == "iteration_limit"
+        eng.solve()
+        a, ta = eng.result(), eng.tree()
+        rc, resident = eng.reduced_costs()
+        assert resident and np.array_equal(rc, inst.cost + ta["pi"][inst.tail] - ta["pi"][inst.head])
+    b, tb = _solve(e, inst, overlap_update=-1, **kw)
+    assert a.status == b.status == "optimal" and a.objective == b.objective
+    assert a.stats["pivots"] == b.stats["pivots"] and a.stats["degenerate"] == b.stats["degenerate"]
+    assert a.stats["arcs_priced"] == b.stats["arcs_priced"]
+    assert np.array_equal(a.flow, b.flow) and np.array_equal(a.potential, b.potential)
+    for key in ("order", "parent", "size", "pos", "depth", "psize"):
+        assert np.array_equal(ta[key], tb[key]), key
+
+
 @pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
 @pytest.mark.parametrize("name", ["netgen_8_12a", "goto_8_12a"])
 def test_persistent_loop_equals_kernel_per_phase_path(gpu_engine_module, name, rule):
