@@ -112,6 +112,14 @@ typedef struct mcf_options {
                                 only the reduced-cost half of the update): 1 = on, 0 / -1 = off.  Same pivot sequence.  Measured
                                 slower at every size (two cross-queue edges per pivot cost ~12 us on this stack;
                                 profiles/r02_ab_overlapped_graph.txt), so auto never picks it: kept as an A/B switch. */
+    int32_t key_mode;        /* key variant of the Dantzig / candidate-list sweep = the reference's specialised entering rules
+                                (specialized_pivots.py:69-424, dispatch :452-527) as variants of the one kernel:
+                                0 = plain violation (also the transportation row scan :69-117; forward_first = 1 selects 1),
+                                1 = forward candidates first (assignment, :191-223),
+                                2 = candidates flagged in arc_priority first (shortest path :338-424, bipartite matching :233-281),
+                                3 = capacity x violation (max flow, :284-335).  Not with MCF_RULE_DEVEX_BLOCK. */
+    const int8_t* arc_priority; /* key_mode 2: one byte per arc, caller's order; bit 0 = preferred as a forward candidate (flow rises
+                                from the lower bound), bit 1 = preferred as a backward candidate.  Read during mcf_create only. */
 } mcf_options;
 
 typedef struct mcf_stats {

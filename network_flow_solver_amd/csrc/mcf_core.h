@@ -32,6 +32,13 @@
 
 #define MCF_INF ((int64_t)1 << 60)  // "uncapacitated" sentinel; also ratio-test infinity
 
+// bit pattern of a double (positive doubles order like their bit patterns: merits travel as 64-bit integer keys)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define mcf_double_bits(x) ((int64_t)__double_as_longlong(x))
+#else
+static inline int64_t mcf_double_bits(double x) { int64_t k; __builtin_memcpy(&k, &x, 8); return k; }
+#endif
+
 // Team primitives of the cooperative passes (mcf_pivot_scan): a workgroup on the device, a single
 // "lane" in the host emulation build (where a barrier is nothing and an atomic is a plain update).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -259,9 +266,8 @@ struct McfView {
     McfSeg* seg;            // [2*n_nodes + 2] scratch
     McfCtx* ctx;
     // ---- resident reduced costs (large instances; nullptr = price by gathering potentials)
-    int32_t fwd_first;      // 1: forward candidates outrank backward ones in the Dantzig key (the reference's min-cost rule for
-                            // assignment problems looks at forward arcs only and leaves the rest to the pricing strategy,
-                            // specialized_pivots.py:191-223 + simplex.py:1061-1064)
+    int32_t key_mode;       // MCF_KEY_*: how the Dantzig / candidate-list key is formed from an eligible arc's violation (the
+                            // reference's specialised entering rules as variants of the one sweep, specialized_pivots.py:69-424)
     int32_t rc_partial;     // 1: a sharded handle keeps rcache exact for ITS OWN shard only (the patch walks a per-rank
                             // adjacency: 1/G of the work); single arcs outside the sweep are then priced from the potentials
     int64_t* rcache;        // [m_pad] rc of every arc under the current potentials, engine order
@@ -270,6 +276,7 @@ struct McfView {
     // violation does not fit: then the sweep looks the exact value up.  A Dantzig / candidate-list sweep reads these
     // 4 bytes per arc instead of 8 B reduced cost + 1 B state.  Kept exact by the same passes that keep rcache exact.
     int32_t* vkey;          // [m_pad] or nullptr
+    const int8_t* prio;     // [m_pad] MCF_KEY_PRIORITY: bit 0 = the arc is preferred as a forward candidate, bit 1 = as a backward one
     int64_t vk_bigm;        // big-M of the instance (level spacing of the code)
     int32_t vk_half;        // half width of a level: violations within +-vk_half of a multiple of big-M are coded exactly
     int32_t vk_pad;
@@ -335,11 +342,34 @@ MCF_HD int64_t mcf_vkey_decode(int32_t code, int64_t bigm, int32_t half) {
     return j * bigm + d;
 }
 
-// Dantzig key of an eligible arc: its violation; with fwd_first a forward arc (state > 0) carries bit 61 on top, so every
-// forward candidate beats every backward one and the violation still orders each group (violations stay below 2^46).
+// Dantzig key of an eligible arc (engine index i, violation viol > 0, state +-1).  The reference's specialised entering rules
+// (specialized_pivots.py) are all "scan every arc, keep the best by some merit, else fall back to the general rule"; here
+// each is a way of forming the key, so one sweep serves them all:
+//   MCF_KEY_PLAIN          the violation (Dantzig; the row scan for transportation problems, :69-117, is exactly this)
+//   MCF_KEY_FORWARD_FIRST  every forward candidate outranks every backward one, the violation orders each group (min-cost
+//                          rule for assignment problems: forward arcs only, the rest left to the pricing strategy, :191-223)
+//   MCF_KEY_PRIORITY       candidates flagged in prio[] (bit 0 as forward, bit 1 as backward candidate) outrank the others
+//                          (shortest path, :338-424: forward arcs whose tail the source reaches, and every backward arc;
+//                          bipartite matching, :233-281: arcs leaving the unit-supply side)
+//   MCF_KEY_CAPACITY       merit = capacity x violation as a double (max flow, :284-335: residual x |reduced cost|; an
+//                          eligible non-basic arc's residual is its capacity); uncapacitated arcs: +inf, as in the reference
+// Bit 61 marks the preferred group: violations stay below 2^46.  Positive doubles order like their bit patterns.
 #define MCF_FWD_BIT ((int64_t)1 << 61)
-MCF_HD int64_t mcf_dantzig_key(int32_t fwd_first, int64_t viol, int32_t state) {
-    return (fwd_first && state > 0) ? (viol | MCF_FWD_BIT) : viol;
+#define MCF_KEY_PLAIN 0
+#define MCF_KEY_FORWARD_FIRST 1
+#define MCF_KEY_PRIORITY 2
+#define MCF_KEY_CAPACITY 3
+MCF_HD int64_t mcf_dantzig_key(const McfView& v, int64_t i, int64_t viol, int32_t state) {
+    switch (v.key_mode) {
+        case MCF_KEY_FORWARD_FIRST: return state > 0 ? (viol | MCF_FWD_BIT) : viol;
+        case MCF_KEY_PRIORITY: return (v.prio[i] & (state > 0 ? 1 : 2)) ? (viol | MCF_FWD_BIT) : viol;
+        case MCF_KEY_CAPACITY: {
+            const int64_t cap = v.arcw[i].cap;
+            const double merit = cap >= MCF_INF ? __builtin_huge_val() : (double)cap * (double)viol;
+            return mcf_double_bits(merit);
+        }
+        default: return viol;
+    }
 }
 
 MCF_HD bool mcf_cand_better(int64_t key, int64_t arc, int64_t bkey, int64_t barc) {
@@ -474,7 +504,7 @@ MCF_HD int64_t mcf_minor_key(const McfView& v, int64_t packed_arc) {
     if (s == 0) return 0;
     const int64_t rc = (v.rcache && !v.rc_partial) ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
     const int64_t viol = -s * rc;
-    return viol > 0 ? mcf_dantzig_key(v.fwd_first, viol, (int32_t)s) : 0;
+    return viol > 0 ? mcf_dantzig_key(v, e, viol, (int32_t)s) : 0;
 }
 
 // ---------------------------------------------------------------------------

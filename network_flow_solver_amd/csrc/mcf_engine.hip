@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shar
                     const int64_t rc = (int64_t)cs[k] + pt[u][k] - ph[u][k];
                     const int64_t viol = -(int64_t)s * rc;
                     if (viol <= 0) continue;
-                    int64_t kk = mcf_dantzig_key(v.fwd_first, viol, s);
+                    int64_t kk = mcf_dantzig_key(v, i, viol, s);
                     if (RULE == MCF_RULE_DEVEX_BLOCK) {
                         const double merit = ((double)viol * (double)viol) / (double)ws[k];
                         kk = __double_as_longlong(merit);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
                     if (s == 0 || i < lo || i >= hi) continue;
                     const int64_t viol = -(int64_t)s * rcs[k];
                     if (viol <= 0) continue;
-                    int64_t kk = mcf_dantzig_key(v.fwd_first, viol, s);
+                    int64_t kk = mcf_dantzig_key(v, i, viol, s);
                     if (RULE == MCF_RULE_DEVEX_BLOCK) {
                         const double merit = ((double)viol * (double)viol) / (double)ws[k];
                         kk = __double_as_longlong(merit);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
                 if (i < hi && state[i]) {
                     const int64_t viol = -(int64_t)state[i] * rcache[i];
                     if (viol > 0) {
-                        key = mcf_dantzig_key(v.fwd_first, viol, (int32_t)state[i]);
+                        key = mcf_dantzig_key(v, i, viol, (int32_t)state[i]);
                         if (rule == MCF_RULE_DEVEX_BLOCK) key = __double_as_longlong(((double)viol * (double)viol) / (double)v.weight[i]);
                         best_i = i;
                         best_s = state[i];
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
                     if (!sts[u]) continue;
                     const int64_t viol = -(int64_t)sts[u] * rcs[u];
                     if (viol <= 0) continue;
-                    int64_t kk = mcf_dantzig_key(v.fwd_first, viol, sts[u]);
+                    int64_t kk = mcf_dantzig_key(v, i, viol, sts[u]);
                     if (rule == MCF_RULE_DEVEX_BLOCK) {
                         const double merit = ((double)viol * (double)viol) / (double)wts[u];
                         kk = __double_as_longlong(merit);
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
                 if (!v.state[i]) continue;
                 const int64_t viol = mcf_violation(v, i);
                 if (viol <= 0) continue;
-                int64_t kk = mcf_dantzig_key(v.fwd_first, viol, (int32_t)v.state[i]);
+                int64_t kk = mcf_dantzig_key(v, i, viol, (int32_t)v.state[i]);
                 if (rule == MCF_RULE_DEVEX_BLOCK) {
                     const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
                     kk = __double_as_longlong(merit);
@@ -1178,6 +1178,7 @@ struct mcf_handle {
     // device arrays
     int32_t *d_tail = nullptr, *d_head = nullptr, *d_cost = nullptr, *d_orig = nullptr;
     int8_t* d_state = nullptr;
+    int8_t* d_prio = nullptr;    // MCF_KEY_PRIORITY: per-arc preference bits, engine order
     float* d_weight = nullptr;
     McfArcW* d_arcw = nullptr;
     int64_t* d_pi = nullptr;
@@ -1504,7 +1505,7 @@ void free_all(mcf_handle* h) {
     for (hipEvent_t e : h->fork_ev) (void)hipEventDestroy(e);
     if (h->side) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : h->loop_ev) if (e) (void)hipEventDestroy(e);
-    (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_weight);
+    (void)hipFree(h->d_tail); (void)hipFree(h->d_head); (void)hipFree(h->d_cost); (void)hipFree(h->d_orig); (void)hipFree(h->d_state); (void)hipFree(h->d_prio); (void)hipFree(h->d_weight);
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
     (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_reach); (void)hipFree(h->d_chg); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_dx); (void)hipFree(h->d_full_tab);
@@ -1542,6 +1543,11 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     mcf_options opt;
     if (opt_in) opt = *opt_in; else mcf_default_options(&opt);
     if (opt.abi_version != MCF_ABI_VERSION) { g_create_error = "mcf_options.abi_version mismatch"; return MCF_E_BAD_ARG; }
+    if (opt.key_mode < 0 || opt.key_mode > MCF_KEY_CAPACITY || (opt.key_mode == MCF_KEY_PRIORITY && !opt.arc_priority) ||
+        (opt.key_mode > 0 && opt.rule == MCF_RULE_DEVEX_BLOCK)) {
+        g_create_error = "mcf_options.key_mode: 0..3, MCF_KEY_PRIORITY needs arc_priority, and the key variants belong to the Dantzig / candidate-list rules";
+        return MCF_E_BAD_ARG;
+    }
     if (opt.rule != MCF_RULE_DANTZIG_FULL && opt.rule != MCF_RULE_DEVEX_BLOCK && opt.rule != MCF_RULE_CANDIDATE_LIST) {
         g_create_error = "unknown pricing rule";
         return MCF_E_BAD_ARG;
@@ -1621,7 +1627,16 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     for (int x = 0; x <= MCF_NUM_BUCKETS; ++x) v.bucket_off[x] = im.bucket_off[x];
     v.weight = opt.rule == MCF_RULE_DEVEX_BLOCK ? h->d_weight : nullptr;
     v.dx = nullptr;  // (allocated and filled by upload_image for the Devex rule)
-    v.fwd_first = opt.forward_first ? 1 : 0;
+    // key variant of the Dantzig / candidate-list sweep (the reference's specialised entering rules, mcf_core.h: mcf_dantzig_key)
+    v.key_mode = opt.key_mode > 0 ? opt.key_mode : (opt.forward_first ? MCF_KEY_FORWARD_FIRST : MCF_KEY_PLAIN);
+    v.prio = nullptr;
+    if (v.key_mode == MCF_KEY_PRIORITY) {
+        std::vector<int8_t> pr((size_t)im.m_pad, 0);   // the caller's order -> engine order
+        for (int64_t i = 0; i < im.m; ++i) pr[(size_t)i] = (int8_t)(opt.arc_priority[im.orig[(size_t)i]] & 3);
+        if ((e = dalloc(&h->d_prio, im.m_pad)) != hipSuccess) return fail("hipMalloc priority", e);
+        if ((e = hipMemcpy(h->d_prio, pr.data(), pr.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy priority", e);
+        v.prio = h->d_prio;
+    }
     v.arcw = h->d_arcw; v.pi = h->d_pi; v.node = h->d_node;
     v.order[0] = h->d_order0; v.order[1] = h->d_order1;
     v.posbuf[0] = h->d_pos0; v.posbuf[1] = h->d_pos1;
@@ -1726,7 +1741,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     // byte and a 4-byte store per patched arc (k_update +1..3 us per pivot), which a candidate-list handle (one sweep per ~33
     // pivots) or an incremental sweep (1 % of the arcs re-read per pivot) never earns back.  compressed_keys: 1 = on, -1 = off.
     const bool keys_auto = opt.rule == MCF_RULE_DANTZIG_FULL && opt.full_sweeps > 0 && im.m >= kIncrementalMinArcs;
-    if (h->rcached && !h->mid && opt.rule != MCF_RULE_DEVEX_BLOCK && !opt.forward_first &&
+    if (h->rcached && !h->mid && opt.rule != MCF_RULE_DEVEX_BLOCK && v.key_mode == MCF_KEY_PLAIN &&
         (opt.compressed_keys > 0 || (opt.compressed_keys == 0 && keys_auto))) {
         if ((e = dalloc(&h->d_vkey, im.m_pad)) != hipSuccess) return fail("hipMalloc vkey", e);
         v.vkey = h->d_vkey;
@@ -1988,7 +2003,8 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const bool found = h->h_one->key > 0 && h->h_one->arc >= 0;
     *arc = found ? ((h->h_one->arc >> 32) & (MCF_DIR_FLAG - 1)) : -1;  // caller's arc index (Devex ids carry the direction in bit 30)
-    if (key) *key = found ? (rule == MCF_RULE_DEVEX_BLOCK ? h->h_one->key : (h->h_one->key & ~MCF_FWD_BIT)) : 0;
+    // Devex and the capacity-weighted variant report their merit (bit pattern of the double), the other variants the violation
+    if (key) *key = found ? ((rule == MCF_RULE_DEVEX_BLOCK || h->view.key_mode == MCF_KEY_CAPACITY) ? h->h_one->key : (h->h_one->key & ~MCF_FWD_BIT)) : 0;
     if (dir) {
         *dir = 0;
         if (found) {

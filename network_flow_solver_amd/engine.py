@@ -25,6 +25,7 @@ RULE_DEVEX_BLOCK = 1
 RULE_CANDIDATE_LIST = 2
 STATUS_NAMES = {0: "optimal", 1: "infeasible", 2: "iteration_limit", 3: "unbounded"}
 CAP_INF = -1
+KEY_PLAIN, KEY_FORWARD_FIRST, KEY_PRIORITY, KEY_CAPACITY = 0, 1, 2, 3   # mcf_options.key_mode
 
 # every symbol include/mcf.h declares (tests check that the library exports each one)
 ABI_SYMBOLS = (
@@ -55,7 +56,7 @@ class McfOptions(ctypes.Structure):
         ("cycle_scan", ctypes.c_int32), ("mid_loop", ctypes.c_int32), ("full_sweeps", ctypes.c_int32),
         ("devex_tuner", ctypes.c_int32), ("devex_stay", ctypes.c_int32), ("forward_first", ctypes.c_int32),
         ("compressed_keys", ctypes.c_int32), ("vkey_half_log2", ctypes.c_int32), ("climb_depth", ctypes.c_int32),
-        ("overlap_update", ctypes.c_int32),
+        ("overlap_update", ctypes.c_int32), ("key_mode", ctypes.c_int32), ("arc_priority", ctypes.POINTER(ctypes.c_int8)),
     ]
 
 
@@ -160,7 +161,7 @@ class McfEngine:
                  shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
                  resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0, full_sweeps: int = 0,
                  devex_tuner: int = 0, devex_stay: bool = False, forward_first: bool = False, compressed_keys: int = 0,
-                 vkey_half_log2: int = 0, climb_depth: int = 0, overlap_update: int = 0):
+                 vkey_half_log2: int = 0, climb_depth: int = 0, overlap_update: int = 0, key_mode: int = 0, arc_priority=None):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -197,6 +198,16 @@ class McfEngine:
         opt.forward_first = 1 if forward_first else 0
         opt.compressed_keys = int(compressed_keys)   # 0 auto (on for the Dantzig-key grid sweeps), -1 off
         opt.vkey_half_log2 = int(vkey_half_log2)
+        # key variant of the Dantzig / candidate-list sweep (the reference's specialised entering rules): KEY_PLAIN,
+        # KEY_FORWARD_FIRST (= forward_first), KEY_PRIORITY (arc_priority: bit 0 forward, bit 1 backward), KEY_CAPACITY
+        self.key_mode = int(key_mode) if key_mode else (KEY_FORWARD_FIRST if forward_first else KEY_PLAIN)
+        opt.key_mode = self.key_mode
+        self._arc_priority = None
+        if int(key_mode) == KEY_PRIORITY:
+            self._arc_priority = np.ascontiguousarray(arc_priority, dtype=np.int8)
+            if self._arc_priority.shape[0] != len(tail):
+                raise ValueError("arc_priority needs one byte per arc")
+            opt.arc_priority = _p(self._arc_priority, ctypes.c_int8)
         opt.overlap_update = int(overlap_update)     # 1 = pricing of pivot t+1 beside the permutation of pivot t (A/B switch: measured slower)
         opt.climb_depth = int(climb_depth)           # 0 auto, -1 never, k: end points of depth <= k are climbed outright
         if shard is not None:

@@ -31,7 +31,7 @@ from . import engine as _engine
 from .data import (ArrayBasis, Basis, FlowResult, LazyDuals, LazyFlows, NetworkProblem, ProgressCallback, ProgressInfo,
                    SoAProblem, SolverOptions)
 from .exceptions import InvalidProblemError, SolverConfigurationError, UnboundedProblemError
-from .specializations import NetworkType, analyze_network_structure
+from .specializations import analyze_network_structure, entering_rule_options
 
 _MAX_DECIMALS = 9
 
@@ -214,19 +214,17 @@ class NetworkSimplex:
         # simplex.py:133-137, 259-261 + specialized_pivots.py:452-527: structured instances get the reference's
         # specialised entering rule, as a variant of the same sweep kernel
         self.network_structure = analyze_network_structure(problem)
-        forward_first = False
-        if self.network_structure.network_type is NetworkType.TRANSPORTATION:
-            self.pricing_rule = _engine.RULE_DANTZIG          # row scan (:69-117) == full-scan Dantzig
-            self.logger.info("Using specialized pivot strategy for transportation")
-        elif self.network_structure.network_type is NetworkType.ASSIGNMENT:
-            self.pricing_rule, forward_first = _engine.RULE_DANTZIG, True   # min-cost forward scan first (:191-223)
-            self.logger.info("Using specialized pivot strategy for assignment")
+        special = entering_rule_options(self.network_structure, self.flat.node_ids, self.flat.tail, self.flat.head, self.flat.supply,
+                                        unit=self.flat.flow_scale)
+        if special is not None:
+            self.pricing_rule = special.pop("rule")
+            self.logger.info(f"Using specialized pivot strategy for {self.network_structure.network_type.value}")
         bs = self.options.block_size
         block_size = 0 if bs is None or isinstance(bs, str) else int(bs)
         self.engine = _engine.McfEngine(
             len(self.flat.node_ids), self.flat.tail, self.flat.head, self.flat.cost, self.flat.cap,
             self.flat.supply, rule=self.pricing_rule, block_size=block_size, batch_pivots=batch_pivots,
-            use_graph=use_graph, device=device, forward_first=forward_first)
+            use_graph=use_graph, device=device, **(special or {}))
         self.stats: dict = {}
 
     # simplex.py:314-374: the reference's grid-on-torus heuristic switches to Dantzig unless the

@@ -14,9 +14,11 @@ TRANSPORTATION         row scan = most violating arc in either direction, first 
                        (specialized_pivots.py:69-117): exactly the full-scan Dantzig kernel
 ASSIGNMENT             min-cost scan over forward arcs only, the general rule for what is left
                        (:191-223): the Dantzig kernel with ``forward_first`` keys
-BIPARTITE_MATCHING,    the reference's heuristics there (first arc out of an unmatched node,
-MAX_FLOW,              residual x |rc| merit, label-gated Dantzig) all hand over to the general
-SHORTEST_PATH          pricing rule when they find nothing; the engine uses the general rule at once
+SHORTEST_PATH          label-gated Dantzig (:338-424): forward arcs whose tail the source reaches and every
+                       backward arc first, the general rule for the rest: ``key_mode = KEY_PRIORITY``
+BIPARTITE_MATCHING     arcs leaving the unit-supply nodes of the left partition first (:233-281; the engine
+                       only ever enters improving arcs): ``KEY_PRIORITY``
+MAX_FLOW               merit = residual x |reduced cost| (:284-335): ``KEY_CAPACITY``
 =====================  ==========================================================================
 """
 
@@ -141,3 +143,41 @@ def analyze_network_structure(problem) -> NetworkStructure:
         kind = NetworkType.MAX_FLOW
     out.network_type = kind
     return out
+
+
+def entering_rule_options(structure: NetworkStructure, node_ids, tail: np.ndarray, head: np.ndarray, supply: np.ndarray,
+                          unit: int = 1) -> dict | None:
+    """Engine options (``McfEngine`` keyword arguments) of the specialised entering rule the reference would pick for this
+    structure (specialized_pivots.py:452-527), or None for the general pricing rule.  ``tail`` / ``head`` / ``supply``
+    are the solver's flat integer arrays (supplies in multiples of 1 / ``unit``), ``node_ids`` the ids in the same node order.  Every variant is a key of the
+    Dantzig sweep (``mcf_core.h: mcf_dantzig_key``), so the rule is RULE_DANTZIG with a ``key_mode``."""
+    from . import engine as _engine
+
+    kind = structure.network_type
+    n = int(supply.shape[0])
+    if kind is NetworkType.TRANSPORTATION:                       # row scan == the plain full-scan Dantzig kernel
+        return {"rule": _engine.RULE_DANTZIG}
+    if kind is NetworkType.ASSIGNMENT:
+        return {"rule": _engine.RULE_DANTZIG, "key_mode": _engine.KEY_FORWARD_FIRST}
+    if kind is NetworkType.MAX_FLOW:                             # needs a source and a sink (:488-503)
+        if (supply > 0).any() and (supply < 0).any():
+            return {"rule": _engine.RULE_DANTZIG, "key_mode": _engine.KEY_CAPACITY}
+        return None
+    if kind is NetworkType.SHORTEST_PATH:                        # one unit from a source to a sink (:505-522)
+        src = np.flatnonzero(supply == unit)
+        if src.size == 0 or not (supply == -unit).any():
+            return None
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import breadth_first_order
+
+        graph = coo_matrix((np.ones(tail.shape[0], dtype=np.int8), (tail, head)), shape=(n, n)).tocsr()
+        reached = np.zeros(n, dtype=bool)
+        reached[breadth_first_order(graph, int(src[0]), directed=True, return_predecessors=False)] = True
+        prio = np.where(reached[tail], 3, 2).astype(np.int8)     # bit 1: every backward candidate; bit 0: forward with a labelled tail
+        return {"rule": _engine.RULE_DANTZIG, "key_mode": _engine.KEY_PRIORITY, "arc_priority": prio}
+    if kind is NetworkType.BIPARTITE_MATCHING and structure.partitions is not None and structure.partitions[0]:
+        left = structure.partitions[0]
+        in_left = np.fromiter((nid in left for nid in node_ids), dtype=bool, count=n)
+        prio = (in_left[tail] & (supply[tail] == unit)).astype(np.int8)
+        return {"rule": _engine.RULE_DANTZIG, "key_mode": _engine.KEY_PRIORITY, "arc_priority": prio}
+    return None

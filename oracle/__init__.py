@@ -393,7 +393,7 @@ def _load_emul():
         lib.emul_solve.argtypes = [
             ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, ctypes.c_int32, ctypes.c_int64,
             ctypes.c_int64, i32p, i64p, i64p, i64p, i8p, i64p, i32p, i32p, i32p, i32p, i32p, i64p, ctypes.c_int64,
-            ctypes.c_int32, i32p, i32p, ctypes.c_int32, i64p, i8p, i8p, i32p,
+            ctypes.c_int32, i32p, i32p, ctypes.c_int32, i64p, i8p, i8p, i32p, i8p,
         ]
         _emul = lib
     return _emul
@@ -417,10 +417,11 @@ def emul_check_block_map(inst, price_blocks: int, shard: int = 0, shards: int = 
 
 def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0, max_pivots: int = -1,
                trace: int = 0, bucketed: bool = True, climb_budget: int = -1,
-               warm_in_tree=None, warm_at_upper=None) -> dict:
+               warm_in_tree=None, warm_at_upper=None, arc_priority=None) -> dict:
     """Run the engine's integer pivot algorithm on the CPU. Arrays are 0-based ints; cap < 0 = inf.
     climb_budget < 0: the cycle is always found by pointer chasing; k >= 0: after k round trips the
-    position-space scan (mcf_pivot_scan) takes over."""
+    position-space scan (mcf_pivot_scan) takes over.  Bits 8-9 of `rule`: mcf_options.key_mode (1 forward first,
+    2 arc_priority, 3 capacity-weighted)."""
     lib = _load_emul()
     m = int(len(tail))
     tail = np.ascontiguousarray(tail, np.int32)
@@ -440,6 +441,7 @@ def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int 
     wt = None if warm_in_tree is None else np.ascontiguousarray(warm_in_tree, np.int8)
     wu = None if warm_at_upper is None else np.ascontiguousarray(warm_at_upper, np.int8)
     warm_applied = ctypes.c_int32(0)
+    pr = None if arc_priority is None else np.ascontiguousarray(arc_priority, np.int8)
     rc = lib.emul_solve(
         n, m, _ptr(tail, ctypes.c_int32), _ptr(head, ctypes.c_int32), _ptr(cost, ctypes.c_int64),
         _ptr(cap, ctypes.c_int64), _ptr(supply, ctypes.c_int64), rule, block_size, max_pivots,
@@ -448,7 +450,8 @@ def emul_solve(n, tail, head, cost, cap, supply, rule: int = 0, block_size: int 
         _ptr(pred, ctypes.c_int32), _ptr(size, ctypes.c_int32), _ptr(pos, ctypes.c_int32),
         _ptr(order, ctypes.c_int32), _ptr(tr, ctypes.c_int64), trace, 1 if bucketed else 0, _ptr(depth, ctypes.c_int32),
         _ptr(psize, ctypes.c_int32), climb_budget, _ptr(scan_stats, ctypes.c_int64),
-        None if wt is None else _ptr(wt, ctypes.c_int8), None if wu is None else _ptr(wu, ctypes.c_int8), ctypes.byref(warm_applied))
+        None if wt is None else _ptr(wt, ctypes.c_int8), None if wu is None else _ptr(wu, ctypes.c_int8), ctypes.byref(warm_applied),
+        None if pr is None else _ptr(pr, ctypes.c_int8))
     if rc != 0:
         raise RuntimeError(f"emul_solve failed with code {rc}")
     objective = (int(obj[0]) << 64) + (int(obj[1]) & ((1 << 64) - 1))
@@ -466,12 +469,12 @@ class EmulStepper:
     """Step-wise handle on the CPU emulation (one replica): price a shard, apply a pivot.
     Mirrors how the HIP engine is driven per pivot in the arc-sharded multi-GPU loop."""
 
-    def __init__(self, n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0, bucketed: bool = True):
+    def __init__(self, n, tail, head, cost, cap, supply, rule: int = 0, block_size: int = 0, bucketed: bool = True, arc_priority=None):
         lib = _load_emul()
         i32p, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
         lib.emul_create.restype = ctypes.c_void_p
         lib.emul_create.argtypes = [ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i64p, i64p, ctypes.c_int32, ctypes.c_int64,
-                                    ctypes.c_int32]
+                                    ctypes.c_int32, ctypes.POINTER(ctypes.c_int8)]
         lib.emul_price.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, i64p]
         lib.emul_price.restype = None
         lib.emul_pivot.argtypes = [ctypes.c_void_p, i64p, ctypes.c_int32]
@@ -498,9 +501,11 @@ class EmulStepper:
                       np.ascontiguousarray(cost, np.int64), np.ascontiguousarray(cap, np.int64),
                       np.ascontiguousarray(supply, np.int64)]
         t, h, c, cp, s = self._keep
+        pr = None if arc_priority is None else np.ascontiguousarray(arc_priority, np.int8)
         self._h = lib.emul_create(int(n), self.m, _ptr(t, ctypes.c_int32), _ptr(h, ctypes.c_int32),
                                   _ptr(c, ctypes.c_int64), _ptr(cp, ctypes.c_int64), _ptr(s, ctypes.c_int64),
-                                  int(rule), int(block_size), 1 if bucketed else 0)
+                                  int(rule), int(block_size), 1 if bucketed else 0,
+                                  None if pr is None else _ptr(pr, ctypes.c_int8))
         if not self._h:
             raise RuntimeError("emul_create failed")
 

@@ -27,7 +27,8 @@ struct Emul {
     McfCtx ctx{};
     McfView view{};    // value-initialised: every optional pointer of the view starts out null
     int rule = 0;
-    int fwd_first = 0;          // bit 8 of the `rule` argument: forward candidates first (mcf_options.forward_first)
+    int key_mode = 0;           // bits 8-9 of the `rule` argument: MCF_KEY_* (mcf_options.key_mode / forward_first)
+    std::vector<int8_t> prio;   // MCF_KEY_PRIORITY: preference bits per arc, engine order
     int price_blocks = 8;
     std::vector<McfCand> cand;  // candidate-list rule: one entry per (virtual) pricing workgroup
     McfDevex dx;                // Devex: granule table + touched-weight list
@@ -71,7 +72,8 @@ void bind(Emul& e) {
     v.rec2 = e.rec2.data();
     v.seg = e.seg.data();
     v.ctx = &e.ctx;
-    v.fwd_first = e.fwd_first;
+    v.key_mode = e.key_mode;
+    v.prio = e.prio.empty() ? nullptr : e.prio.data();
     v.rc_partial = 0;
     v.vkey = nullptr;   // (the compressed keys ride on the resident reduced costs, which the emulation does not keep)
     v.vk_bigm = im.big_m; v.vk_half = 1 << 28; v.vk_pad = 0;
@@ -115,7 +117,7 @@ int64_t price(Emul& e, int64_t r, int64_t G, int64_t* key, int64_t* arc) {
             if (!v.state[i]) continue;
             const int64_t viol = mcf_violation(v, i);
             if (viol <= 0) continue;
-            int64_t kk = mcf_dantzig_key(v.fwd_first, viol, v.state[i]);
+            int64_t kk = mcf_dantzig_key(v, i, viol, v.state[i]);
             if (e.rule == MCF_RULE_DEVEX_BLOCK) {
                 const double merit = ((double)viol * (double)viol) / (double)v.weight[i];
                 std::memcpy(&kk, &merit, 8);
@@ -192,14 +194,19 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
                int64_t* stats /*[12]*/, int32_t* parent, int32_t* pred_arc, int32_t* size, int32_t* pos,
                int32_t* order, int64_t* trace_arcs, int64_t trace_cap, int32_t bucketed, int32_t* depth, int32_t* psize,
                int32_t climb_budget /* < 0: always climb */, int64_t* scan_stats /*[2] or null*/,
-               const int8_t* warm_in_tree /* null: cold start */, const int8_t* warm_at_upper, int32_t* warm_applied) {
+               const int8_t* warm_in_tree /* null: cold start */, const int8_t* warm_at_upper, int32_t* warm_applied,
+               const int8_t* arc_priority /* MCF_KEY_PRIORITY: caller's order; else null */) {
     Emul e;
     e.rule = rule & 0xff;
-    e.fwd_first = (rule >> 8) & 1;
+    e.key_mode = (rule >> 8) & 3;
     rule = e.rule;
     int err = 0;
     std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e.im, &err, bucketed != 0);
     if (err) { std::fprintf(stderr, "emul_solve: %s\n", msg.c_str()); return err; }
+    if (e.key_mode == MCF_KEY_PRIORITY && arc_priority) {   // the caller's order -> engine order
+        e.prio.assign((size_t)e.im.m_pad, 0);
+        for (int64_t i = 0; i < e.im.m; ++i) e.prio[(size_t)i] = (int8_t)(arc_priority[e.im.orig[(size_t)i]] & 3);
+    }
     if (warm_applied) *warm_applied = 0;
     if (warm_in_tree) {  // same host routine the HIP library's mcf_set_basis runs
         const std::string why = mcf_apply_basis(e.im, warm_in_tree, warm_at_upper);
@@ -265,13 +272,18 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
 // ---- step-wise API: lets the multi-process (gloo) tests drive one replica per rank exactly
 // the way the HIP engine is driven per pivot (price shard -> all-gather -> pivot).
 void* emul_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, const int64_t* cost,
-                  const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int32_t bucketed) {
+                  const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int32_t bucketed,
+                  const int8_t* arc_priority) {
     Emul* e = new Emul();
     e->rule = rule & 0xff;
-    e->fwd_first = (rule >> 8) & 1;
+    e->key_mode = (rule >> 8) & 3;
     int err = 0;
     std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e->im, &err, bucketed != 0);
     if (err) { std::fprintf(stderr, "emul_create: %s\n", msg.c_str()); delete e; return nullptr; }
+    if (e->key_mode == MCF_KEY_PRIORITY && arc_priority) {   // the caller's order -> engine order
+        e->prio.assign((size_t)e->im.m_pad, 0);
+        for (int64_t i = 0; i < e->im.m; ++i) e->prio[(size_t)i] = (int8_t)(arc_priority[e->im.orig[(size_t)i]] & 3);
+    }
     bind(*e);
     McfCtx& c = e->ctx;
     c.max_pivots = INT64_MAX;

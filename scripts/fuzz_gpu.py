@@ -31,7 +31,10 @@ while time.time() < t_end and runs < max_runs:
                 full_sweeps=rng.choice([-1, 0, 1]), use_graph=rng.random() < 0.7, batch_pivots=rng.choice([7, 32, 64]),
                 climb_depth=rng.choice([-1, 0, 0, 2, 9]),                                   # depth gate of the cycle search
                 compressed_keys=rng.choice([-1, 1, 1]), vkey_half_log2=rng.choice([0, 0, 9, 14]),   # key codes, narrow levels
-                forward_first=rule != 1 and rng.random() < 0.2)                              # assignment-style keys
+                key_mode=rng.choice([0, 0, 0, 1, 2, 3]) if rule != 1 else 0,                 # the specialised entering rules' keys
+                overlap_update=rng.choice([0, 0, 1]))                                        # two-stream graphs
+    prio = np.random.default_rng(seed).integers(0, 4, size=len(inst.tail)).astype(np.int8) if opts["key_mode"] == 2 else None
+    opts["arc_priority"] = prio
     cost = inst.cost * rng.choice([1, 1, 300])                                               # x300: big-M >= 2^29 (level coding)
     if int(np.abs(cost).max()) * (inst.n + 2) >= 2 ** 43:
         cost = inst.cost
@@ -39,8 +42,8 @@ while time.time() < t_end and runs < max_runs:
     cap = rng.choice([10 ** 9, 10 ** 9, 137, 2500])
     if inst.n > 30000:
         cap = rng.choice([2500, 12000, 40000])   # (a full emulated solve takes minutes at this size)
-    em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule | (0x100 if opts["forward_first"] else 0),
-                           max_pivots=cap)
+    em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule | (opts["key_mode"] << 8),
+                           max_pivots=cap, arc_priority=prio)
     try:
         with engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, **opts) as eng:
             if rng.random() < 0.3 and cap > 200:          # budgeted prefix + resume
@@ -67,13 +70,13 @@ while time.time() < t_end and runs < max_runs:
             detail = {"flow_diffs": int((r.flow != em["flow"]).sum()), "pot_diffs": int((r.potential != em["potential"]).sum()),
                       "order_diffs": int((t["order"] != em["order"]).sum()), "deg": [int(r.stats["degenerate"]), em["degenerate"]],
                       "status": [r.status, em["status"]], "minor": [int(r.stats.get("cycle_scans", -1))]}
-        msg = json.dumps({"seed": seed, "family": fam, "n": inst.n, "m": inst.m, "rule": rule, "opts": opts, "cap": cap,
+        msg = json.dumps({"seed": seed, "family": fam, "n": inst.n, "m": inst.m, "rule": rule, "opts": {k: v for k, v in opts.items() if k != "arc_priority"}, "cap": cap,
                           "gpu_pivots": None if r is None else r.stats["pivots"], "emul_pivots": em["pivots"], "detail": detail,
                           "previous_run": prev_cfg})
         print("MISMATCH", msg, flush=True)
         with log.open("a") as fh:
             fh.write(msg + "\n")
-    prev_cfg = {"seed": seed, "family": fam, "n": inst.n, "rule": rule, "opts": opts, "cap": cap}
+    prev_cfg = {"seed": seed, "family": fam, "n": inst.n, "rule": rule, "opts": {k: v for k, v in opts.items() if k != "arc_priority"}, "cap": cap}
     seed += 1
     if runs % 50 == 0:
         print(f"  ... {runs} runs, {fails} mismatches, {t_end - time.time():.0f} s left", flush=True)   # (a silent GPU command is killed)

@@ -222,3 +222,48 @@ def test_restated_block_selection_tie_rules():
     assert oracle.price_block(tail, head, cost, pot, fwd, bwd, in_tree, w, 3, 6) == (3, -1, 9.0)
     assert oracle.price_block(tail, head, cost, pot, fwd, bwd, in_tree, w, 4, 5) is None
     del inf
+
+
+@pytest.mark.parametrize("rule", [0, 2], ids=["dantzig", "candidate_list"])
+def test_key_variants_reach_the_same_optimum(rule):
+    """The specialised entering rules as key variants (mcf_core.h: mcf_dantzig_key; specialized_pivots.py:191-424): a different
+    pivot order, the same optimum, on every synthetic golden the emulation solves."""
+    for entry, inst in load_synthetic()[:8]:
+        exp = next(iter(entry["expected"].values()))
+        rng = np.random.default_rng(inst.m)
+        prio = rng.integers(0, 4, size=inst.m).astype(np.int8)
+        counts = set()
+        for key_mode, pr in ((0, None), (1, None), (2, prio), (3, None)):
+            em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule | (key_mode << 8), arc_priority=pr)
+            assert em["status"] == "optimal" and em["objective"] == int(round(exp["objective"])), (entry["name"], key_mode)
+            check_optimality(inst, em["flow"], em["potential"])
+            counts.add(em["pivots"])
+        assert len(counts) > 1
+
+
+def test_entering_rule_options_follow_the_reference_dispatch():
+    """specialized_pivots.py:452-527: which key variant each structured class gets, and what the priority bytes hold."""
+    from network_flow_solver_amd import engine as e
+    from network_flow_solver_amd.specializations import NetworkStructure, NetworkType, entering_rule_options
+
+    # a path 0 -> 1 -> 2 plus a node 3 the source does not reach (arc 3 -> 2)
+    tail, head = np.array([0, 1, 3], np.int32), np.array([1, 2, 2], np.int32)
+    supply = np.array([1, 0, -1, 0], np.int64)
+    ids = ["a", "b", "c", "d"]
+    st = NetworkStructure(NetworkType.SHORTEST_PATH, False)
+    opt = entering_rule_options(st, ids, tail, head, supply)
+    assert opt["rule"] == e.RULE_DANTZIG and opt["key_mode"] == e.KEY_PRIORITY
+    assert opt["arc_priority"].tolist() == [3, 3, 2]           # backward always; forward only where the tail is labelled
+    assert entering_rule_options(st, ids, tail, head, np.array([2, 0, -2, 0], np.int64)) is None     # no unit source: general rule
+    assert entering_rule_options(st, ids, tail, head, np.array([2, 0, -2, 0], np.int64), unit=2)["key_mode"] == e.KEY_PRIORITY
+    st = NetworkStructure(NetworkType.MAX_FLOW, False)
+    assert entering_rule_options(st, ids, tail, head, supply) == {"rule": e.RULE_DANTZIG, "key_mode": e.KEY_CAPACITY}
+    assert entering_rule_options(st, ids, tail, head, np.zeros(4, np.int64)) is None
+    st = NetworkStructure(NetworkType.BIPARTITE_MATCHING, True, partitions=({"a", "d"}, {"b", "c"}))
+    opt = entering_rule_options(st, ids, np.array([0, 3, 0], np.int32), np.array([1, 2, 2], np.int32), np.array([1, -1, -1, 1], np.int64))
+    assert opt["key_mode"] == e.KEY_PRIORITY and opt["arc_priority"].tolist() == [1, 1, 1]
+    opt = entering_rule_options(st, ids, np.array([0, 3, 0], np.int32), np.array([1, 2, 2], np.int32), np.array([1, -1, -2, 2], np.int64))
+    assert opt["arc_priority"].tolist() == [1, 0, 1]            # only unit-supply nodes of the left side count as unmatched
+    assert entering_rule_options(NetworkStructure(NetworkType.ASSIGNMENT, True), ids, tail, head, supply)["key_mode"] == e.KEY_FORWARD_FIRST
+    assert entering_rule_options(NetworkStructure(NetworkType.TRANSPORTATION, True), ids, tail, head, supply) == {"rule": e.RULE_DANTZIG}
+    assert entering_rule_options(NetworkStructure(NetworkType.GENERAL, False), ids, tail, head, supply) is None

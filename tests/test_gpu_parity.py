@@ -9,6 +9,9 @@
 
 Integer / index work throughout, so every comparison is exact (no tolerance)."""
 
+import json
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -733,6 +736,102 @@ def test_forward_first_keys_on_every_engine_path(gpu_engine_module, rule):
         got = eng.price_once(0)
         pi = eng.tree()["pi"]
         assert got[2] == abs(int(inst.cost[got[0]] + pi[inst.tail[got[0]]] - pi[inst.head[got[0]]]))
+
+
+@pytest.mark.parametrize("rule", [0, 2], ids=["dantzig", "candidate_list"])
+@pytest.mark.parametrize("mode", ["priority", "capacity"])
+def test_key_variants_on_every_engine_path(gpu_engine_module, rule, mode):
+    """mcf_options.key_mode 2 / 3 (the reference's shortest-path / bipartite-matching preference classes and its max-flow
+    merit capacity x violation, specialized_pivots.py:233-424, as keys of the one sweep): every engine path pivots
+    exactly like the CPU emulation with the same key and ends at the plain rule's optimum."""
+    e = gpu_engine_module
+    for idx, kws in ((3, ({}, {"fused": False}, {"fused": False, "mid_loop": -1})), (7, ({}, {"mid_loop": -1}, {"resident_rc": False}))):
+        _, inst = load_synthetic()[idx]
+        rng = np.random.default_rng(idx)
+        prio = rng.integers(0, 4, size=inst.m).astype(np.int8) if mode == "priority" else None
+        key_mode = e.KEY_PRIORITY if mode == "priority" else e.KEY_CAPACITY
+        em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule | (key_mode << 8), arc_priority=prio)
+        plain, _ = _solve(e, inst, rule)
+        for kw in kws:
+            res, tree = _solve(e, inst, rule, key_mode=key_mode, arc_priority=prio, **kw)
+            assert res.status == "optimal" and res.objective == em["objective"] == plain.objective
+            assert res.stats["pivots"] == em["pivots"] and np.array_equal(res.flow, em["flow"])
+            assert np.array_equal(tree["order"], em["order"])
+        assert em["pivots"] != plain.stats["pivots"]
+    # one selection against a direct restatement of the two keys
+    with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0, key_mode=key_mode, arc_priority=prio,
+                     fused=False, mid_loop=-1) as eng:
+        eng.solve(max_pivots=50)
+        res, pi = eng.result(), eng.tree()["pi"]
+        rc = inst.cost + pi[inst.tail] - pi[inst.head]
+        at_upper = ~res.in_tree & (inst.cap > 0) & (res.flow == inst.cap)
+        state = np.where(res.in_tree | (inst.cap == 0), 0, np.where(at_upper, -1, 1))
+        viol = -state * rc
+        elig = viol > 0
+        if mode == "priority":
+            merit = np.where(elig, viol.astype(np.int64) + ((prio & np.where(state > 0, 1, 2)) != 0).astype(np.int64) * (1 << 61), -1)
+        else:
+            merit = np.where(elig, np.where(inst.cap < 0, np.inf, inst.cap.astype(np.float64)) * viol, -1.0)
+        got = eng.price_once(0)
+        assert merit[got[0]] == merit.max() and got[0] == int(np.flatnonzero(merit == merit.max())[0])
+
+
+def _structured_instances():
+    """(kind, nodes, arcs, what the reference itself returned) of tests/golden/structured_cases.json."""
+    data = json.loads((Path(__file__).parent / "golden" / "structured_cases.json").read_text())
+    return [(c["network_type"], c["nodes"], c["arcs"], c["expected"]) for c in data]
+
+
+def test_the_shim_maps_every_structured_class_to_its_key(gpu_engine_module):
+    """Shortest-path, bipartite-matching and max-flow problems through the shim: the structure analysis agrees with the
+    restated reference classification, selects the key variant (specialized_pivots.py:452-527), and the optimum equals
+    the one the restated reference (with ITS specialised strategy) reaches.  The reference's own fixtures of these
+    classes (an unbounded cycle, a capacity-starved instance) keep their outcome."""
+    e = gpu_engine_module
+    want = {"shortest_path": e.KEY_PRIORITY, "bipartite_matching": e.KEY_PRIORITY, "max_flow": e.KEY_CAPACITY, "assignment": e.KEY_FORWARD_FIRST}
+    for kind, nodes, arcs, expected in _structured_instances():
+        assert oracle.detect_network_type(nodes, arcs, True, 1e-6)[0] == kind
+        ref = oracle.solve_dicts(nodes, arcs, True, 1e-6, "devex", max_iterations=2000)
+        assert (ref.status, ref.iterations) == (expected["devex"]["status"], expected["devex"]["iterations"])
+        if kind == "bipartite_matching":
+            # the reference's matching heuristic enters the first arc out of an unmatched node whatever its reduced cost
+            # (:253-281) and runs into the iteration limit on a real matching instance (the fixture holds what the
+            # reference itself returned; the oracle reproduces it); the optimum to meet is the general rule's
+            assert ref.status == "iteration_limit"
+            ref = oracle.solve_dicts(nodes, arcs, True, 1e-6, "devex", special=oracle.SPECIAL_TYPES["general"])
+        assert ref.status == "optimal"
+        for strategy in ("devex", "dantzig"):
+            problem = nfs.build_problem(nodes, arcs, True, 1e-6)
+            solver = nfs.NetworkSimplex(problem, nfs.SolverOptions(pricing_strategy=strategy, explicit_pricing_strategy=True))
+            try:
+                assert solver.network_structure.network_type.value == kind
+                assert solver.pricing_rule == e.RULE_DANTZIG and solver.engine.key_mode == want[kind]
+                res = solver.solve()
+            finally:
+                solver.engine.close()
+            assert res.status == "optimal" and res.objective == pytest.approx(ref.objective, abs=1e-9)
+            if ref.min_nonbasic_abs_rc is not None and ref.min_nonbasic_abs_rc > 1e-9:     # unique optimum: same flows
+                assert {k: v for k, v in res.flows.items() if abs(v) > 1e-9} == pytest.approx(ref.flows)
+    seen = set()
+    for case in CASES:
+        if case["network_type"] not in want:
+            continue
+        exp = case["expected"]["devex"]
+        problem = nfs.build_problem(case["nodes"], case["arcs"], case["directed"], case["tolerance"])
+        solver = nfs.NetworkSimplex(problem, nfs.SolverOptions(pricing_strategy="devex", explicit_pricing_strategy=True))
+        try:
+            assert solver.network_structure.network_type.value == case["network_type"]
+            assert solver.engine.key_mode == want[case["network_type"]]
+            if exp["status"] == "unbounded":
+                with pytest.raises(nfs.UnboundedProblemError):
+                    solver.solve()
+            else:
+                res = solver.solve()
+                assert res.status == exp["status"] and res.objective == pytest.approx(exp["objective"], abs=1e-9)
+        finally:
+            solver.engine.close()
+        seen.add(case["network_type"])
+    assert seen == set(want)
 
 
 def test_structured_problems_take_the_specialised_rules(gpu_engine_module):

@@ -60,6 +60,27 @@ def test_pivot_counts_match_reference_on_every_case(case, strategy):
     assert res.iterations == exp["iterations"]
 
 
+def _structured_cases():
+    import json
+    from pathlib import Path
+    return json.loads((Path(__file__).parent / "golden" / "structured_cases.json").read_text())
+
+
+@pytest.mark.parametrize("case", _structured_cases(), ids=lambda c: c["name"])
+@pytest.mark.parametrize("strategy", STRATS)
+def test_specialised_strategies_on_real_structured_instances(case, strategy):
+    """Shortest-path, max-flow and bipartite-matching instances of some size (tests/golden/make_structured.py ran the
+    reference on them): the oracle classifies them like the reference and reproduces its status, objective, pivot count
+    and flows -- including the bipartite-matching heuristic's failure to terminate (iteration limit after 2 000 pivots)."""
+    exp = case["expected"][strategy]
+    assert oracle.detect_network_type(case["nodes"], case["arcs"], True, case["tolerance"])[0] == case["network_type"]
+    res = oracle.solve_dicts(case["nodes"], case["arcs"], True, case["tolerance"], strategy, max_iterations=case["max_iterations"])
+    assert (res.status, res.iterations) == (exp["status"], exp["iterations"])
+    assert res.objective == pytest.approx(exp["objective"], abs=1e-9)
+    if res.status == "optimal" and res.min_nonbasic_abs_rc > 1e-6:
+        assert res.flows == pytest.approx({(t, h): f for t, h, f in exp["flows"] if abs(f) > 1e-9})
+
+
 def test_specialised_strategies_change_the_pivot_sequence():
     """The specialised rules are not a no-op: switched off (special=0), at least one transportation fixture takes a
     different number of pivots than the reference did."""
