@@ -32,13 +32,14 @@ from .exceptions import (
     UnboundedProblemError,
 )
 from .simplex import NetworkSimplex
-from .solver import load_problem, save_result, solve_min_cost_flow
+from .solver import load_problem, save_result, solve_many, solve_min_cost_flow
 
 __all__ = [
     "Arc", "Basis", "FlowResult", "NetworkProblem", "Node", "ProgressCallback", "ProgressInfo", "SoAProblem", "SolverOptions",
     "build_problem", "parse_dimacs_file", "parse_dimacs_soa", "parse_dimacs_string", "InfeasibleProblemError",
     "InvalidProblemError", "IterationLimitError", "NetworkSolverError", "NumericalInstabilityError",
     "SolverConfigurationError", "UnboundedProblemError", "NetworkSimplex", "load_problem", "save_result",
+    "solve_many",
     "solve_min_cost_flow",
 ]
 

@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -917,6 +918,7 @@ struct SmallLayout {
 };
 
 constexpr int kSmallThreads = 1024;
+constexpr int kSmallMaxLds = 158 * 1024;   // dynamic LDS of the fused small-instance loop (160 KB per CU, a little static on top)
 
 __device__ __forceinline__ void copy_words(void* dst, const void* src, uint32_t bytes) {
     const uint32_t n = bytes >> 2;
@@ -938,9 +940,10 @@ __device__ __forceinline__ void copy_words(void* dst, const void* src, uint32_t 
 #define STAMP(slot) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallLayout L, int32_t rule,
-                                                                McfCand* __restrict__ list, int64_t cap) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// The whole solve of one LDS-resident instance by one workgroup (k_solve_small: one instance per launch;
+// k_solve_small_batch: one instance per workgroup of the launch)
+__device__ __forceinline__ void solve_small_body(const McfView& g, const SmallLayout& L, int32_t rule,
+                                                 McfCand* __restrict__ list, int64_t cap, char* smem) {
 #ifdef MCF_STAMPS
     unsigned long long stamps_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
@@ -1153,6 +1156,30 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallL
         for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i];
     }
 #endif
+}
+
+__global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallLayout L, int32_t rule,
+                                                                McfCand* __restrict__ list, int64_t cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    solve_small_body(g, L, rule, list, cap, smem);
+}
+
+// Many independent small instances side by side: workgroup b solves jobs[b] from start to finish in its own CU's LDS.
+// Nothing is shared between the workgroups, so a batch of >= 256 instances keeps every CU of the chip busy with
+// latency-bound work that a single instance can only ever give one CU of (mcf_solve_batch).
+struct SmallJob {
+    McfView g;
+    SmallLayout L;
+    int32_t rule;
+    int32_t pad;
+    McfCand* list;
+    int64_t cap;
+};
+
+__global__ __launch_bounds__(kSmallThreads) void k_solve_small_batch(const SmallJob* __restrict__ jobs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SmallJob& J = jobs[blockIdx.x];   // uniform per workgroup: scalar loads
+    solve_small_body(J.g, J.L, J.rule, J.list, J.cap, smem);
 }
 
 // ------------------------------------------------------------------ k_ctl: (re)arm the control block
@@ -1659,10 +1686,21 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         L.seg = take((2 * Nn + 2) * sizeof(McfSeg)); L.ctx = take(sizeof(McfCtx));
         L.total = off;
         const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 112 + 4096;
-        h->small = !opt.no_fused && !opt.profile && h->shards == 1 && need < 150 * 1024 && L.total <= 158 * 1024;
+        h->small = !opt.no_fused && !opt.profile && h->shards == 1 && need < 150 * 1024 && L.total <= kSmallMaxLds;
         if (h->small) {
-            hipError_t fe = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+            // (the limit is a property of the kernel, not of the handle: it only ever grows, so that handles of different
+            //  sizes can be alive together -- and share one batched launch)
+            static std::mutex lds_mu;
+            static int lds_limit = 0;
+            std::lock_guard<std::mutex> lock(lds_mu);
+            hipError_t fe = hipSuccess;
+            if ((int)L.total > lds_limit) {
+                fe = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+                if (fe == hipSuccess) fe = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small_batch),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+                if (fe == hipSuccess) lds_limit = (int)L.total;
+                else (void)hipGetLastError();   // (the refusal must not surface later as some launch's error)
+            }
             if (fe != hipSuccess) h->small = false;  // fall back to the three-kernel GPU path
         }
     }
@@ -1900,6 +1938,83 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
     h->stats.solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     h->solved_once = true;
     return MCF_OK;
+}
+
+// Independent small instances side by side: one launch, one persistent LDS-resident workgroup per handle.
+int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* max_pivots, double* kernel_ms) {
+    if (!handles || count <= 0) return MCF_E_BAD_ARG;
+    mcf_handle* h0 = handles[0];
+    if (!h0) return MCF_E_BAD_ARG;
+    for (int32_t i = 0; i < count; ++i) {
+        mcf_handle* h = handles[i];
+        if (!h) return MCF_E_BAD_ARG;
+        if (!h->small || h->shards != 1 || h->device != h0->device) {
+            h0->err = "mcf_solve_batch: every handle must be on the fused LDS path (mcf_stats.pricing_mode 2) of one device";
+            return MCF_E_STATE;
+        }
+        for (int32_t j = 0; j < i; ++j)
+            if (handles[j] == h) { h0->err = "mcf_solve_batch: a handle appears twice"; return MCF_E_BAD_ARG; }
+    }
+    HIP_TRY(h0, hipSetDevice(h0->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<SmallJob> jobs((size_t)count);
+    uint32_t lds = 0;
+    for (int32_t i = 0; i < count; ++i) {
+        mcf_handle* h = handles[i];
+        int rc = sync_ctx(h, h->stream);   // (also drains whatever the handle's own stream still holds)
+        if (rc) return rc;
+        h->external_driver = false;
+        const int64_t m = h->im.m, n = h->im.n;
+        int64_t mp = max_pivots ? max_pivots[i] : -1;
+        if (mp < 0) mp = 20 * (m + n) > 100 ? 20 * (m + n) : 100;  // simplex.py:1470
+        SmallJob& J = jobs[(size_t)i];
+        J.g = h->view; J.L = h->small_layout; J.rule = h->opt.rule; J.pad = 0; J.list = h->d_cand;
+        J.cap = h->h_ctx->pivots + mp;
+        if (h->small_layout.total > lds) lds = h->small_layout.total;
+    }
+    SmallJob* d_jobs = nullptr;
+    McfCtx* h_all = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    auto cleanup = [&]() {
+        if (d_jobs) (void)hipFree(d_jobs);
+        if (h_all) (void)hipHostFree(h_all);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    };
+    auto bail = [&](const char* what, hipError_t e) {
+        h0->err = std::string(what) + ": " + hipGetErrorString(e);
+        cleanup();
+        return MCF_E_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&d_jobs), jobs.size() * sizeof(SmallJob))) != hipSuccess) return bail("hipMalloc jobs", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_all), (size_t)count * sizeof(McfCtx), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipEventCreate(&ev[0])) != hipSuccess || (e = hipEventCreate(&ev[1])) != hipSuccess) return bail("hipEventCreate", e);
+    hipStream_t s = h0->stream;
+    if ((e = hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(SmallJob), hipMemcpyHostToDevice, s)) != hipSuccess) return bail("hipMemcpy jobs", e);
+    if ((e = hipEventRecord(ev[0], s)) != hipSuccess) return bail("hipEventRecord", e);
+    hipLaunchKernelGGL(k_solve_small_batch, dim3((unsigned)count), dim3(kSmallThreads), lds, s, (const SmallJob*)d_jobs);
+    if ((e = hipGetLastError()) != hipSuccess) return bail("k_solve_small_batch", e);
+    if ((e = hipEventRecord(ev[1], s)) != hipSuccess) return bail("hipEventRecord", e);
+    // every control block back in one go (the copies queue up behind the kernel on the same stream)
+    for (int32_t i = 0; i < count; ++i)
+        if ((e = hipMemcpyAsync(&h_all[i], handles[i]->d_ctx, sizeof(McfCtx), hipMemcpyDeviceToHost, s)) != hipSuccess) return bail("hipMemcpy ctx", e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail("hipStreamSynchronize", e);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+    if (kernel_ms) *kernel_ms = ms;
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int ret = MCF_OK;
+    for (int32_t i = 0; i < count; ++i) {
+        mcf_handle* h = handles[i];
+        *h->h_ctx = h_all[i];
+        h->ctx_current = true;
+        h->stats.batches += 1;
+        h->stats.solve_seconds += secs / count;   // the batch's wall time, shared out
+        h->solved_once = true;
+        if (h->h_ctx->status == MCF_INTERNAL_ERROR) { h->err = "internal error: preorder permutation did not close"; ret = MCF_E_INTERNAL; }
+    }
+    cleanup();
+    return ret;
 }
 
 int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int64_t* flow, int64_t* potential,

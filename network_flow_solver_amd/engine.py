@@ -29,7 +29,7 @@ KEY_PLAIN, KEY_FORWARD_FIRST, KEY_PRIORITY, KEY_CAPACITY = 0, 1, 2, 3   # mcf_op
 
 # every symbol include/mcf.h declares (tests check that the library exports each one)
 ABI_SYMBOLS = (
-    "mcf_default_options", "mcf_create", "mcf_solve", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis",
+    "mcf_default_options", "mcf_create", "mcf_solve", "mcf_solve_batch", "mcf_get_result", "mcf_price_once", "mcf_reset", "mcf_set_basis",
     "mcf_enqueue_price", "mcf_enqueue_pivot", "mcf_shard_info", "mcf_enqueue_price_list", "mcf_enqueue_pivots", "mcf_poll", "mcf_set_max_pivots", "mcf_time_pricing",
     "mcf_time_copy", "mcf_get_tree", "mcf_get_reduced_costs", "mcf_get_pricing_keys", "mcf_get_weights", "mcf_dimacs_scan", "mcf_dimacs_load", "mcf_last_error", "mcf_destroy", "mcf_abi_version", "mcf_device_count",
 )
@@ -103,6 +103,7 @@ def load_library():
     lib.mcf_solve.argtypes = [vp, ctypes.c_int64, PROGRESS_CB, vp, ctypes.c_int64]
     lib.mcf_get_result.argtypes = [vp, i32p, i64p, i64p, i64p, i8p, ctypes.POINTER(McfStats)]
     lib.mcf_price_once.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, i64p, i32p, i64p]
+    lib.mcf_solve_batch.argtypes = [ctypes.POINTER(vp), ctypes.c_int32, i64p, ctypes.POINTER(ctypes.c_double)]
     lib.mcf_reset.argtypes = [vp]
     lib.mcf_set_basis.argtypes = [vp, i8p, i8p]
     lib.mcf_enqueue_price.argtypes = [vp, vp, vp]
@@ -413,3 +414,23 @@ def dimacs_load(path: str):
         raise InvalidProblemError(err.value.decode())
     k = m.value
     return n.value, tail[:k], head[:k], lower[:k], cap[:k], cost[:k], supply
+
+
+def solve_batch(engines, max_pivots=None) -> float:
+    """Solve independent small instances side by side: ONE launch, one persistent LDS-resident workgroup per engine
+    (``mcf_solve_batch``).  Every engine must be on the fused LDS path (``stats()["pricing_mode"] == 2``).  ``max_pivots``:
+    None (the reference's default budget everywhere), one int, or one int per engine.  Returns the launch's duration in
+    milliseconds; results through each engine's ``result()`` as after ``solve()``."""
+    engines = list(engines)
+    if not engines:
+        return 0.0
+    lib = engines[0]._lib
+    hs = (ctypes.c_void_p * len(engines))(*[e._h.value for e in engines])
+    caps = None
+    if max_pivots is not None:
+        caps = np.ascontiguousarray(np.broadcast_to(np.asarray(max_pivots, dtype=np.int64), (len(engines),)))
+    ms = ctypes.c_double(0.0)
+    rc = lib.mcf_solve_batch(hs, len(engines), None if caps is None else _p(caps, ctypes.c_int64), ctypes.byref(ms))
+    if rc != 0:
+        engines[0]._check(rc)
+    return float(ms.value)

@@ -302,12 +302,7 @@ class NetworkSimplex:
     def solve(self, max_iterations: int | None = None, progress_callback: ProgressCallback | None = None,
               progress_interval: int = 100, warm_start_basis: Basis | None = None) -> FlowResult:
         """Solve; returns a FlowResult, raises UnboundedProblemError (simplex.py:1446-1765)."""
-        f = self.flat
-        n, m = len(f.node_ids), self.actual_arc_count
-        if max_iterations is None:
-            max_iterations = self.options.max_iterations
-        if max_iterations is None:
-            max_iterations = max(100, 20 * (m + n))               # simplex.py:1470 (len(arcs) incl. artificial)
+        max_iterations = self.default_budget(max_iterations)    # simplex.py:1470 (len(arcs) incl. artificial)
         if warm_start_basis is not None:
             self.logger.info("Attempting to apply warm-start basis")      # simplex.py:1496
             if not self._apply_warm_start_basis(warm_start_basis):
@@ -333,6 +328,20 @@ class NetworkSimplex:
         self.engine.solve(max_iterations, progress, progress_interval)
         if raised:
             raise raised[0]
+        return self._collect()
+
+    def default_budget(self, max_iterations: int | None = None) -> int:
+        """The pivot budget ``solve`` would use (simplex.py:1470)."""
+        if max_iterations is None:
+            max_iterations = self.options.max_iterations
+        if max_iterations is None:
+            max_iterations = max(100, 20 * (self.actual_arc_count + len(self.flat.node_ids)))
+        return int(max_iterations)
+
+    def _collect(self) -> FlowResult:
+        """The engine's final state as the reference's FlowResult (simplex.py:1573-1765); raises UnboundedProblemError."""
+        f = self.flat
+        m = self.actual_arc_count
         res = self.engine.result()
         self.stats = res.stats
         iterations = int(res.stats["pivots"])

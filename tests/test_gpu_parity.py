@@ -1128,3 +1128,65 @@ def test_million_node_instance_solved_to_certified_optimality(gpu_engine_module,
     assert api.status == "optimal" and api.objective == float(res.objective)
     assert api.iterations <= 10_000            # (a few degenerate pivots -- 132 when written -- instead of 3.4 M)
     assert np.array_equal(api.flows.array, res.flow)
+
+
+def test_batched_small_instances_equal_one_by_one(gpu_engine_module):
+    """mcf_solve_batch: independent small instances, one persistent LDS-resident workgroup each in ONE launch -- every
+    instance ends exactly where its own mcf_solve ends (pivots, flows, potentials, tree), rules mixed, budgets and
+    resumes included; handles that are not on the LDS path are refused."""
+    e = gpu_engine_module
+    insts, rules = [], []
+    for k in range(40):
+        n = (40, 96, 160, 256)[k % 4]
+        insts.append(generators.netgen_style(n, n * (4, 8)[k % 2], seed=100 + k) if k % 5 else generators.gridgen_style(8 + k % 7, 9, seed=k))
+        rules.append(k % 3)
+    single = []
+    for inst, rule in zip(insts, rules):
+        single.append(_solve(e, inst, rule))
+    engines = [e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule) for inst, rule in zip(insts, rules)]
+    try:
+        assert all(eng.stats()["pricing_mode"] == 2 for eng in engines)
+        ms = e.solve_batch(engines, max_pivots=17)                   # a budget first ...
+        assert ms > 0 and all(eng.stats()["pivots"] == min(17, s[0].stats["pivots"]) for eng, s in zip(engines, single))
+        e.solve_batch(engines[:7], max_pivots=[1, 2, 3, 4, 5, 6, 7])     # ... per-handle budgets on a part of the batch ...
+        e.solve_batch(engines)                                       # ... then to the end
+        for eng, (res0, tree0), inst in zip(engines, single, insts):
+            res, tree = eng.result(), eng.tree()
+            assert res.status == res0.status == "optimal" and res.objective == res0.objective
+            assert res.stats["pivots"] == res0.stats["pivots"] and res.stats["degenerate"] == res0.stats["degenerate"]
+            assert np.array_equal(res.flow, res0.flow) and np.array_equal(res.potential, res0.potential)
+            assert np.array_equal(tree["order"], tree0["order"]) and np.array_equal(tree["parent"], tree0["parent"])
+            check_optimality(inst, res.flow, res.potential)
+        e.solve_batch(engines)                                       # solved handles: a no-op
+        assert engines[0].result().stats["pivots"] == single[0][0].stats["pivots"]
+        big = generators.named_instance("netgen_8_12a")
+        with e.McfEngine(big.n, big.tail, big.head, big.cost, big.cap, big.supply, rule=0) as other:
+            with pytest.raises(e.EngineError) as err:
+                e.solve_batch([engines[0], other])
+            assert err.value.code == -6
+    finally:
+        for eng in engines:
+            eng.close()
+
+
+def test_solve_many_equals_solving_one_by_one(gpu_engine_module):
+    """solve_many: the reference's small fixtures (optimal, infeasible, unbounded, alternative optima, every structured
+    class) in one batched launch -- each result is what solve_min_cost_flow returns for that problem."""
+    problems = [nfs.build_problem(c["nodes"], c["arcs"], c["directed"], c["tolerance"]) for c in CASES]
+    batch = nfs.solve_many(problems, nfs.SolverOptions(pricing_strategy="dantzig", explicit_pricing_strategy=True), return_exceptions=True)
+    assert len(batch) == len(CASES)
+    n_exc = 0
+    for case, problem, got in zip(CASES, problems, batch):
+        try:
+            one = nfs.solve_min_cost_flow(problem, nfs.SolverOptions(pricing_strategy="dantzig", explicit_pricing_strategy=True))
+        except nfs.NetworkSolverError as exc:
+            assert type(got) is type(exc) and str(got) == str(exc), case["name"]
+            n_exc += 1
+            continue
+        assert (got.status, got.iterations, got.objective) == (one.status, one.iterations, one.objective), case["name"]
+        assert dict(got.flows) == dict(one.flows) and dict(got.duals) == dict(one.duals), case["name"]
+        exp = case["expected"]["dantzig"]
+        assert got.status == exp["status"] and got.objective == pytest.approx(exp["objective"], abs=1e-9)
+    assert n_exc >= 1
+    with pytest.raises(nfs.UnboundedProblemError):
+        nfs.solve_many(problems)
