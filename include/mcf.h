@@ -173,13 +173,15 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
  * the reference's default budget max(100, 20 * (m + n)), simplex.py:1470). */
 int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user, int64_t cb_interval);
 
-/* Solve `count` INDEPENDENT small instances side by side: one launch, one persistent LDS-resident workgroup (one CU) per
- * handle, each running its whole solve as mcf_solve would (same pivot sequence, same budget rule; no progress callback).
+/* Solve `count` INDEPENDENT instances side by side: one persistent workgroup (one CU) per handle, each running its whole
+ * solve as mcf_solve would (same pivot sequence, same budget rule; no progress callback), all in one launch per engine path.
  * The reference solves instances one after the other on one core (benchmarks/runners/run_benchmark.py; its published
  * per-instance figures are all for <= 4 096 nodes): a single such instance can only ever occupy one CU of 256, a batch
- * fills the chip.  Every handle must be on the fused LDS path (mcf_stats.pricing_mode == 2: about <= 300 nodes / 2 500
- * arcs) and on the same device; max_pivots: one budget per handle (< 0: the reference's default) or NULL for the default
- * everywhere; kernel_ms (optional) <- duration of the one launch.  Results per handle through mcf_get_result as usual. */
+ * fills the chip.  Every handle must run as one persistent workgroup -- the fused LDS path (mcf_stats.pricing_mode == 2:
+ * about <= 300 nodes / 2 500 arcs) or the persistent loop over global state (pricing_mode == 3, Dantzig / Devex;
+ * mcf_options.mid_loop = 1 asks for it at any size) -- on the same device; max_pivots: one budget per handle (< 0: the
+ * reference's default) or NULL for the default everywhere; kernel_ms (optional) <- duration of the launches.  Results per
+ * handle through mcf_get_result as usual. */
 int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* max_pivots, double* kernel_ms);
 
 /* Copy the solution out.  Any pointer may be NULL.  objective_hi_lo[0..1] = high and low

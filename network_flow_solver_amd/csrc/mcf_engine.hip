@@ -678,8 +678,8 @@ __device__ __forceinline__ void arm_ctx(McfCtx* c, int64_t cap) {
     if (c->status == MCF_PIVOT_LIMIT && c->pivots < cap) c->status = MCF_RUNNING;
 }
 
-__global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t rule, const McfCand* __restrict__ cand,
-                                                              int ncand, int fresh, int max_iters, int arm, int64_t cap) {
+__device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, const McfCand* __restrict__ cand,
+                                               int ncand, int fresh, int max_iters, int arm, int64_t cap) {
     __shared__ PivotShared S;
     __shared__ int32_t s_gran[MCF_NUM_BUCKETS][MCF_GRANULES + 1];  // Devex: the granule table (blocks move and resize under the tuner)
     __shared__ int32_t s_lo[MCF_NUM_BUCKETS], s_hi[MCF_NUM_BUCKETS];  // other rules: the whole buckets
@@ -827,6 +827,25 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
 #ifdef MCF_STAMPS
     if (threadIdx.x == 0) for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i];
 #endif
+}
+
+__global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t rule, const McfCand* __restrict__ cand,
+                                                              int ncand, int fresh, int max_iters, int arm, int64_t cap) {
+    solve_mid_body(g, rule, cand, ncand, fresh, max_iters, arm, cap);
+}
+
+// Many independent instances side by side, state in global memory: workgroup b runs the whole solve of jobs[b]
+// (Dantzig / Devex handles of the persistent loop; mcf_solve_batch).
+struct MidJob {
+    McfView g;
+    int32_t rule;
+    int32_t pad;
+    int64_t cap;
+};
+
+__global__ __launch_bounds__(kPivotThreads) void k_solve_mid_batch(const MidJob* __restrict__ jobs) {
+    const MidJob& J = jobs[blockIdx.x];   // uniform per workgroup: scalar loads
+    solve_mid_body(J.g, J.rule, nullptr, 0, 0, 1 << 22, 1, J.cap);
 }
 
 // The reduced-cost half alone (overlapped graphs: the next pivot's pricing waits for this half only, see build_graph)
@@ -1940,7 +1959,8 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
     return MCF_OK;
 }
 
-// Independent small instances side by side: one launch, one persistent LDS-resident workgroup per handle.
+// Independent instances side by side: one launch per engine path, one persistent workgroup per handle
+// (k_solve_small_batch: whole instance in LDS; k_solve_mid_batch: state in global memory, Dantzig / Devex).
 int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* max_pivots, double* kernel_ms) {
     if (!handles || count <= 0) return MCF_E_BAD_ARG;
     mcf_handle* h0 = handles[0];
@@ -1948,8 +1968,10 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
     for (int32_t i = 0; i < count; ++i) {
         mcf_handle* h = handles[i];
         if (!h) return MCF_E_BAD_ARG;
-        if (!h->small || h->shards != 1 || h->device != h0->device) {
-            h0->err = "mcf_solve_batch: every handle must be on the fused LDS path (mcf_stats.pricing_mode 2) of one device";
+        const bool loop = h->small || (h->mid && h->opt.rule != MCF_RULE_CANDIDATE_LIST);
+        if (!loop || h->shards != 1 || h->device != h0->device) {
+            h0->err = "mcf_solve_batch: every handle must run as ONE persistent workgroup -- mcf_stats.pricing_mode 2 (LDS loop) or 3 "
+                      "(persistent loop, Dantzig / Devex; mcf_options.mid_loop = 1 asks for it at any size) -- on one device";
             return MCF_E_STATE;
         }
         for (int32_t j = 0; j < i; ++j)
@@ -1957,7 +1979,8 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
     }
     HIP_TRY(h0, hipSetDevice(h0->device));
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<SmallJob> jobs((size_t)count);
+    std::vector<SmallJob> small_jobs;
+    std::vector<MidJob> mid_jobs;
     uint32_t lds = 0;
     for (int32_t i = 0; i < count; ++i) {
         mcf_handle* h = handles[i];
@@ -1967,16 +1990,25 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
         const int64_t m = h->im.m, n = h->im.n;
         int64_t mp = max_pivots ? max_pivots[i] : -1;
         if (mp < 0) mp = 20 * (m + n) > 100 ? 20 * (m + n) : 100;  // simplex.py:1470
-        SmallJob& J = jobs[(size_t)i];
-        J.g = h->view; J.L = h->small_layout; J.rule = h->opt.rule; J.pad = 0; J.list = h->d_cand;
-        J.cap = h->h_ctx->pivots + mp;
-        if (h->small_layout.total > lds) lds = h->small_layout.total;
+        const int64_t cap = h->h_ctx->pivots + mp;
+        if (h->small) {
+            SmallJob J;
+            J.g = h->view; J.L = h->small_layout; J.rule = h->opt.rule; J.pad = 0; J.list = h->d_cand; J.cap = cap;
+            small_jobs.push_back(J);
+            if (h->small_layout.total > lds) lds = h->small_layout.total;
+        } else {
+            MidJob J;
+            J.g = h->view; J.rule = h->opt.rule; J.pad = 0; J.cap = cap;
+            mid_jobs.push_back(J);
+        }
     }
-    SmallJob* d_jobs = nullptr;
+    SmallJob* d_small = nullptr;
+    MidJob* d_mid = nullptr;
     McfCtx* h_all = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     auto cleanup = [&]() {
-        if (d_jobs) (void)hipFree(d_jobs);
+        if (d_small) (void)hipFree(d_small);
+        if (d_mid) (void)hipFree(d_mid);
         if (h_all) (void)hipHostFree(h_all);
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     };
@@ -1986,16 +2018,25 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
         return MCF_E_HIP;
     };
     hipError_t e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&d_jobs), jobs.size() * sizeof(SmallJob))) != hipSuccess) return bail("hipMalloc jobs", e);
+    hipStream_t s = h0->stream;
+    if (!small_jobs.empty()) {
+        if ((e = hipMalloc(reinterpret_cast<void**>(&d_small), small_jobs.size() * sizeof(SmallJob))) != hipSuccess) return bail("hipMalloc jobs", e);
+        if ((e = hipMemcpyAsync(d_small, small_jobs.data(), small_jobs.size() * sizeof(SmallJob), hipMemcpyHostToDevice, s)) != hipSuccess) return bail("hipMemcpy jobs", e);
+    }
+    if (!mid_jobs.empty()) {
+        if ((e = hipMalloc(reinterpret_cast<void**>(&d_mid), mid_jobs.size() * sizeof(MidJob))) != hipSuccess) return bail("hipMalloc jobs", e);
+        if ((e = hipMemcpyAsync(d_mid, mid_jobs.data(), mid_jobs.size() * sizeof(MidJob), hipMemcpyHostToDevice, s)) != hipSuccess) return bail("hipMemcpy jobs", e);
+    }
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_all), (size_t)count * sizeof(McfCtx), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipEventCreate(&ev[0])) != hipSuccess || (e = hipEventCreate(&ev[1])) != hipSuccess) return bail("hipEventCreate", e);
-    hipStream_t s = h0->stream;
-    if ((e = hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(SmallJob), hipMemcpyHostToDevice, s)) != hipSuccess) return bail("hipMemcpy jobs", e);
     if ((e = hipEventRecord(ev[0], s)) != hipSuccess) return bail("hipEventRecord", e);
-    hipLaunchKernelGGL(k_solve_small_batch, dim3((unsigned)count), dim3(kSmallThreads), lds, s, (const SmallJob*)d_jobs);
-    if ((e = hipGetLastError()) != hipSuccess) return bail("k_solve_small_batch", e);
+    if (!small_jobs.empty())
+        hipLaunchKernelGGL(k_solve_small_batch, dim3((unsigned)small_jobs.size()), dim3(kSmallThreads), lds, s, (const SmallJob*)d_small);
+    if (!mid_jobs.empty())
+        hipLaunchKernelGGL(k_solve_mid_batch, dim3((unsigned)mid_jobs.size()), dim3(kPivotThreads), 0, s, (const MidJob*)d_mid);
+    if ((e = hipGetLastError()) != hipSuccess) return bail("mcf_solve_batch launch", e);
     if ((e = hipEventRecord(ev[1], s)) != hipSuccess) return bail("hipEventRecord", e);
-    // every control block back in one go (the copies queue up behind the kernel on the same stream)
+    // every control block back in one go (the copies queue up behind the kernels on the same stream)
     for (int32_t i = 0; i < count; ++i)
         if ((e = hipMemcpyAsync(&h_all[i], handles[i]->d_ctx, sizeof(McfCtx), hipMemcpyDeviceToHost, s)) != hipSuccess) return bail("hipMemcpy ctx", e);
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail("hipStreamSynchronize", e);

@@ -198,7 +198,7 @@ class NetworkSimplex:
     ROOT_NODE = "__network_simplex_root__"
 
     def __init__(self, problem: NetworkProblem, options: SolverOptions | None = None, *, device: int = -1,
-                 batch_pivots: int = 64, use_graph: bool = True):
+                 batch_pivots: int = 64, use_graph: bool = True, engine_options: dict | None = None):
         self.options = options if options is not None else SolverOptions()
         self.logger = logging.getLogger(__name__)
         self.problem = problem
@@ -224,7 +224,7 @@ class NetworkSimplex:
         self.engine = _engine.McfEngine(
             len(self.flat.node_ids), self.flat.tail, self.flat.head, self.flat.cost, self.flat.cap,
             self.flat.supply, rule=self.pricing_rule, block_size=block_size, batch_pivots=batch_pivots,
-            use_graph=use_graph, device=device, **(special or {}))
+            use_graph=use_graph, device=device, **(special or {}), **(engine_options or {}))
         self.stats: dict = {}
 
     # simplex.py:314-374: the reference's grid-on-torus heuristic switches to Dantzig unless the

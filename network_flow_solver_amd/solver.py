@@ -4,7 +4,7 @@ from __future__ import annotations
 
 from pathlib import Path
 
-from .data import Basis, FlowResult, NetworkProblem, ProgressCallback, SolverOptions
+from .data import Basis, FlowResult, NetworkProblem, ProgressCallback, SoAProblem, SolverOptions
 from .io import load_problem as _load_problem_file
 from .io import save_result as _save_result_file
 from .simplex import NetworkSimplex
@@ -32,36 +32,50 @@ def solve_min_cost_flow(
         solver.engine.close()
 
 
+# solve_many: problems up to this many nodes run as ONE persistent workgroup each when there are enough of them to fill
+# CUs (profiles/r02_batched_*: 256 instances of 1 024 / 4 096 / 8 192 nodes -> 11 M / 6.4 M / 4.7 M pivots/s in total,
+# against ~52 K one after the other; a single instance of 16 384 nodes runs at ~0.55x its kernel-per-phase rate this way)
+_BATCH_MAX_NODES = 16384
+_BATCH_MIN_PROBLEMS = 4
+
+
 def solve_many(problems, options: SolverOptions | None = None, max_iterations: int | None = None,
                return_exceptions: bool = False) -> list:
-    """Solve independent problems; the small ones (whole instance in one CU's LDS: up to about 300 nodes / 2 500 arcs) side
-    by side in ONE launch, one persistent workgroup per problem (``mcf_solve_batch``) -- a single such instance can only
-    occupy one of the chip's 256 CUs, a batch fills it (measured: 256 netgen_8_08a-sized solves in 5.4 ms).  Larger
-    problems are solved one after the other.  Each result is what ``solve_min_cost_flow`` returns for that problem;
-    ``UnboundedProblemError`` / ``InvalidProblemError`` are raised unless ``return_exceptions`` (then they take the
-    problem's place in the list).  No reference counterpart: it solves its benchmark instances in a Python loop
-    (benchmarks/runners/run_benchmark.py)."""
+    """Solve independent problems side by side: every problem that can run as ONE persistent workgroup -- the whole instance
+    in a CU's LDS (up to about 300 nodes / 2 500 arcs, any rule) or, with Dantzig / Devex pricing, its state in global
+    memory (up to 16 384 nodes) -- gets one workgroup of one batched launch (``mcf_solve_batch``).  A single such solve can
+    only occupy one of the chip's 256 CUs; a batch fills it (measured: 256 netgen_8_08a-sized solves in 5.4 ms, 256
+    netgen_8_12a-sized ones in 0.40 s).  Everything else is solved one after the other.  Each result is what
+    ``solve_min_cost_flow`` returns for that problem; ``UnboundedProblemError`` / ``InvalidProblemError`` are raised unless
+    ``return_exceptions`` (then they take the problem's place in the list).  No reference counterpart: it solves its
+    benchmark instances in a Python loop (benchmarks/runners/run_benchmark.py)."""
     from . import engine as _engine
 
     solvers: list = []
     out: list = [None] * len(problems)
+    many = len(problems) >= _BATCH_MIN_PROBLEMS
     try:
         for k, problem in enumerate(problems):
             try:
-                solvers.append(NetworkSimplex(problem, options=options))
+                n_nodes = int(problem.supply.shape[0]) if isinstance(problem, SoAProblem) else len(problem.nodes)
+                loop = {"mid_loop": 1} if many and n_nodes <= _BATCH_MAX_NODES else None
+                solvers.append(NetworkSimplex(problem, options=options, engine_options=loop))
             except Exception as exc:  # noqa: BLE001  (InvalidProblemError and friends)
                 if not return_exceptions:
                     raise
                 solvers.append(None)
                 out[k] = exc
-        small = [k for k, sv in enumerate(solvers) if sv is not None and sv.engine.stats()["pricing_mode"] == 2]
-        if small:
-            _engine.solve_batch([solvers[k].engine for k in small], [solvers[k].default_budget(max_iterations) for k in small])
+        batched = {k for k, sv in enumerate(solvers) if sv is not None and
+                   (sv.engine.stats()["pricing_mode"] == 2 or
+                    (sv.engine.stats()["pricing_mode"] == 3 and sv.pricing_rule != _engine.RULE_CANDIDATE_LIST))}
+        if batched:
+            order = sorted(batched)
+            _engine.solve_batch([solvers[k].engine for k in order], [solvers[k].default_budget(max_iterations) for k in order])
         for k, sv in enumerate(solvers):
             if sv is None:
                 continue
             try:
-                out[k] = sv._collect() if k in set(small) else sv.solve(max_iterations=max_iterations)
+                out[k] = sv._collect() if k in batched else sv.solve(max_iterations=max_iterations)
             except Exception as exc:  # noqa: BLE001  (UnboundedProblemError)
                 if not return_exceptions:
                     raise

@@ -1190,3 +1190,52 @@ def test_solve_many_equals_solving_one_by_one(gpu_engine_module):
     assert n_exc >= 1
     with pytest.raises(nfs.UnboundedProblemError):
         nfs.solve_many(problems)
+
+
+def test_batched_persistent_loops_equal_one_by_one(gpu_engine_module):
+    """mcf_solve_batch over persistent-loop handles (state in global memory, one workgroup per instance), mixed with LDS-loop
+    handles in the same call: every instance ends exactly where its own solve ends; candidate-list handles of that path and
+    graph-path handles are refused."""
+    e = gpu_engine_module
+    insts = [generators.netgen_style((300, 700, 1500, 3000)[k % 4], (300, 700, 1500, 3000)[k % 4] * 8, seed=7 + k) for k in range(12)]
+    insts += [generators.netgen_style(128, 1024, seed=50 + k) for k in range(4)]
+    rules = [k % 2 for k in range(len(insts))]
+    single = [_solve(e, inst, rule) for inst, rule in zip(insts, rules)]
+    engines = [e.McfEngine(i.n, i.tail, i.head, i.cost, i.cap, i.supply, rule=r, mid_loop=1) for i, r in zip(insts, rules)]
+    try:
+        assert sorted({eng.stats()["pricing_mode"] for eng in engines}) == [2, 3]
+        e.solve_batch(engines, max_pivots=123)
+        assert all(eng.stats()["pivots"] == min(123, s[0].stats["pivots"]) for eng, s in zip(engines, single))
+        e.solve_batch(engines)
+        for eng, (res0, tree0), inst in zip(engines, single, insts):
+            res, tree = eng.result(), eng.tree()
+            assert res.status == res0.status == "optimal" and res.objective == res0.objective
+            assert res.stats["pivots"] == res0.stats["pivots"] and np.array_equal(res.flow, res0.flow)
+            assert np.array_equal(res.potential, res0.potential) and np.array_equal(tree["order"], tree0["order"])
+            rc, resident = eng.reduced_costs()
+            if resident:
+                assert np.array_equal(rc, inst.cost + tree["pi"][inst.tail] - tree["pi"][inst.head])
+        big = insts[3]   # 3 000 nodes: not an LDS-loop handle
+        with e.McfEngine(big.n, big.tail, big.head, big.cost, big.cap, big.supply, rule=2, mid_loop=1) as lister:
+            with pytest.raises(e.EngineError) as err:
+                e.solve_batch([engines[0], lister])
+            assert err.value.code == -6
+    finally:
+        for eng in engines:
+            eng.close()
+
+
+@pytest.mark.parametrize("strategy", ["devex", "dantzig", "candidate_list"])
+def test_solve_many_batches_mid_size_problems_too(gpu_engine_module, strategy):
+    """solve_many over flat problems of 300 ... 3 000 nodes: Dantzig / Devex problems run as one persistent workgroup each
+    in the batched launch, candidate-list ones one after the other; every result equals the problem's own solve."""
+    insts = [generators.netgen_style(n, 8 * n, seed=11 + k) for k, n in enumerate((300, 700, 1500, 3000, 200, 900))]
+    problems = [nfs.SoAProblem(i.n, i.tail, i.head, i.cost, i.cap, i.supply) for i in insts]
+    opts = nfs.SolverOptions(pricing_strategy=strategy, explicit_pricing_strategy=True)
+    many = nfs.solve_many(problems, opts)
+    for problem, got, inst in zip(problems, many, insts):
+        one = nfs.solve_min_cost_flow(problem, opts)
+        assert (got.status, got.iterations, got.objective) == (one.status, one.iterations, one.objective) and got.status == "optimal"
+        assert np.array_equal(got.flows.array, one.flows.array)
+        ref = oracle.solve_soa(inst, "dantzig", reference_order=False)
+        assert got.objective == ref["objective"]
