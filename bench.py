@@ -310,30 +310,16 @@ def batched_point(rule: int, instances: int = 1024, nodes: int = 256, arcs: int 
     (one CU) per instance in one launch (mcf_solve_batch): LDS-resident at netgen_8_08a size, state in global memory above.
     The headline `value` is one instance on one CU of 256 -- latency-bound by construction; this is the same per-pivot code
     filling the chip, and the GPU-side counterpart of cpu_baseline.all_cores (independent solves on every host core)."""
-    from network_flow_solver_amd import engine, generators
+    from network_flow_solver_amd.batching import measure_batch
 
-    insts = [generators.netgen_style(nodes, arcs, seed=1 + k) for k in range(instances)]
-    engines = [engine.McfEngine(i.n, i.tail, i.head, i.cost, i.cap, i.supply, rule=rule, mid_loop=1) for i in insts]
-    try:
-        engine.solve_batch(engines[:4], max_pivots=5)          # warm-up launch
-        for eng in engines[:4]:
-            eng.reset()
-        t0 = time.perf_counter()
-        ms = engine.solve_batch(engines)
-        wall = time.perf_counter() - t0
-        stats = [eng.stats() for eng in engines]
-        pivots = sum(st["pivots"] for st in stats)
-        arcs_priced = sum(st["arcs_priced"] for st in stats)
-        return {"workload": f"{instances} independent {label}-sized instances ({nodes} nodes / {arcs} arcs, seeds 1..{instances}), whole solves",
-                "pricing": RULE_NAMES[rule], "engine_path": MODE_NAMES.get(int(stats[0]["pricing_mode"]), "?") + ", one persistent workgroup per instance",
-                "launches": 1, "workgroups": instances, "all_optimal": all(st["status"] == "optimal" for st in stats),
-                "pivots": pivots, "kernel_ms": ms, "wall_ms": 1e3 * wall,
-                "pivots_per_sec": pivots / wall, "pivots_per_sec_in_kernel": pivots / (ms * 1e-3),
-                "value": arcs_priced / wall, "unit": "arcs/s", "solves_per_sec": instances / wall,
-                "note": "wall = host call incl. job upload and control-block read-back; handles created beforehand (instances resident in HBM)"}
-    finally:
-        for eng in engines:
-            eng.close()
+    b = measure_batch(rule, instances, nodes, arcs)
+    return {"workload": f"{instances} independent {label}-sized instances ({nodes} nodes / {arcs} arcs, seeds 1..{instances}), whole solves",
+            "pricing": RULE_NAMES[rule], "engine_path": MODE_NAMES.get(b["pricing_mode"], "?") + ", one persistent workgroup per instance",
+            "launches": 1, "workgroups": instances, "all_optimal": b["all_optimal"],
+            "pivots": b["pivots"], "kernel_ms": b["kernel_ms"], "wall_ms": 1e3 * b["wall_s"],
+            "pivots_per_sec": b["pivots"] / b["wall_s"], "pivots_per_sec_in_kernel": b["pivots"] / (b["kernel_ms"] * 1e-3),
+            "value": b["arcs_priced"] / b["wall_s"], "unit": "arcs/s", "solves_per_sec": instances / b["wall_s"],
+            "note": "wall = host call incl. job upload and control-block read-back; handles created beforehand (instances resident in HBM)"}
 
 
 def main():
