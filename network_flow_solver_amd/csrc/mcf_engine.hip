@@ -574,6 +574,7 @@ static_assert(sizeof(McfCtx) % 4 == 0 && kCtxWords <= kPivotThreads, "control bl
 
 // From the chosen entering arc to the updated flows / tree records / apply descriptor.  `v.ctx` must point at
 // S.ctx; (key, arc) valid in thread 0; `priced` = arcs this pass evaluated (accounting).  All threads call it.
+template <int NT = kPivotThreads>   // NT: threads of the calling workgroup
 __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int64_t key, int64_t arc, int32_t rule,
                                             int64_t priced) {
     if (threadIdx.x == 0) {
@@ -594,7 +595,7 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
     const int go = S.go;
     const McfPaths gp = mcf_view_paths(v);                                                    // cycle scratch in global memory
     const McfPaths sp = McfPaths{S.path[0], S.path[1], S.rec[0], S.rec[1], S.ppos[0], S.ppos[1], S.flow[0], S.flow[1]};  // ... and in LDS
-    if (go == 2) mcf_pivot_scan(v, sp, kSmallPath, &S.cy, &S.acc, S.hits, kHitsLds, threadIdx.x, kPivotThreads);  // barriers inside
+    if (go == 2) mcf_pivot_scan(v, sp, kSmallPath, &S.cy, &S.acc, S.hits, kHitsLds, threadIdx.x, NT);  // barriers inside
     // S.cy.small is written by lane 0 at the very end of the scan: lane 0 may use it at once, the others after the barrier.
     // Separate calls for the two scratch locations: each inlined copy works on one known address space.
     if (go && threadIdx.x == 0 && S.ctx.status == MCF_RUNNING) {
@@ -602,8 +603,8 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
     }
     MCF_PSTAMP(8);
     __syncthreads();
-    if (go && S.cy.small) mcf_pivot_finish(v, sp, threadIdx.x, kPivotThreads);  // array updates, one path element per lane
-    else mcf_pivot_finish(v, gp, threadIdx.x, kPivotThreads);
+    if (go && S.cy.small) mcf_pivot_finish(v, sp, threadIdx.x, NT);  // array updates, one path element per lane
+    else mcf_pivot_finish(v, gp, threadIdx.x, NT);
     MCF_PSTAMP(9);
 }
 
@@ -678,6 +679,7 @@ __device__ __forceinline__ void arm_ctx(McfCtx* c, int64_t cap) {
     if (c->status == MCF_PIVOT_LIMIT && c->pivots < cap) c->status = MCF_RUNNING;
 }
 
+template <int NT = kPivotThreads>   // NT: threads of the workgroup (the batched launch also runs narrower workgroups, two per CU)
 __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, const McfCand* __restrict__ cand,
                                                int ncand, int fresh, int max_iters, int arm, int64_t cap) {
     __shared__ PivotShared S;
@@ -690,7 +692,7 @@ __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, c
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&S.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
     const bool devex = rule == MCF_RULE_DEVEX_BLOCK && g.dx;
     if (devex) {
-        for (int q = threadIdx.x; q < MCF_NUM_BUCKETS * (MCF_GRANULES + 1); q += kPivotThreads)
+        for (int q = threadIdx.x; q < MCF_NUM_BUCKETS * (MCF_GRANULES + 1); q += NT)
             (&s_gran[0][0])[q] = (&g.dx->gran[0][0])[q];
     } else if (threadIdx.x < MCF_NUM_BUCKETS) {
         s_lo[threadIdx.x] = (int32_t)g.bucket_off[threadIdx.x];
@@ -724,18 +726,18 @@ __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, c
             const bool minor = minor_left > 0;
             if (!minor && !have_fresh) break;  // a full sweep is due: back to the grid
             have_fresh = false;
-            for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
+            for (int i = threadIdx.x; i < ncand; i += NT) {
                 const McfCand cd = cand[i];
                 const int64_t kk = minor ? mcf_minor_key(v, cd.arc) : cd.key;
                 if (mcf_cand_better(kk, cd.arc, key, arc)) { key = kk; arc = cd.arc; }
             }
             priced = minor ? ncand : v.m;
             if (ncand <= 64) { if (threadIdx.x < 64) wave_argmax(key, arc); }
-            else block_argmax<kPivotThreads>(key, arc);
+            else block_argmax<NT>(key, arc);
         } else {
             // the arc set of k_price_rc for shard 0 of 1: 128 lanes per head bucket, all eight buckets at once,
             // streaming the resident reduced costs
-            constexpr int kPer = kPivotThreads / MCF_NUM_BUCKETS;
+            constexpr int kPer = NT / MCF_NUM_BUCKETS;
             const int x = threadIdx.x / kPer, l = threadIdx.x % kPer;
             const int64_t lo = devex ? s_gran[x][bg0] : s_lo[x], hi = devex ? s_gran[x][bg1] : s_hi[x];
             const int64_t* __restrict__ rcache = v.rcache;
@@ -791,14 +793,14 @@ __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, c
             if (best_i >= 0) arc = mcf_pack_arc(devex ? mcf_devex_tie_id(v.orig[best_i], best_s) : v.orig[best_i], best_i);
             if (threadIdx.x == 0)
                 for (int x2 = 0; x2 < MCF_NUM_BUCKETS; ++x2) priced += devex ? s_gran[x2][bg1] - s_gran[x2][bg0] : s_hi[x2] - s_lo[x2];
-            block_argmax<kPivotThreads>(key, arc);
+            block_argmax<NT>(key, arc);
         }
         MCF_PSTAMP(1);
-        pivot_core(v, S, key, arc, rule, priced);
+        pivot_core<NT>(v, S, key, arc, rule, priced);
         __syncthreads();  // the finish pass's writes (records, sizes, segment table) before the apply pass reads them
         if (S.ctx.apply) {  // (splitting the lanes between the two halves was measured and lost at 4 096 nodes)
-            apply_pass(v, S.ctx, threadIdx.x, kPivotThreads);
-            rcupd_pass(v, S.ctx, threadIdx.x >> 4, kPivotThreads / 16, threadIdx.x & 15);
+            apply_pass(v, S.ctx, threadIdx.x, NT);
+            rcupd_pass(v, S.ctx, threadIdx.x >> 4, NT / 16, threadIdx.x & 15);
         }
         __syncthreads();
         MCF_PSTAMP(10);
@@ -814,7 +816,7 @@ __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, c
         if (threadIdx.x == 0) s_any = 0;
         __syncthreads();
         int any = 0;
-        for (int64_t i = threadIdx.x; i < g.m && !any; i += kPivotThreads) {
+        for (int64_t i = threadIdx.x; i < g.m && !any; i += NT) {
             const int64_t st = g.state[i];
             if (st != 0 && -st * g.rcache[i] > 0) any = 1;
         }
@@ -843,9 +845,12 @@ struct MidJob {
     int64_t cap;
 };
 
-__global__ __launch_bounds__(kPivotThreads) void k_solve_mid_batch(const MidJob* __restrict__ jobs) {
+// 4 waves per SIMD (<= 128 VGPRs): one workgroup of 1 024 or TWO of 512 per CU -- the loop is a chain of dependent memory
+// round trips, so a second instance on the CU fills the first one's waiting time (scripts/batch_mid.py, MCF_BATCH_THREADS).
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void k_solve_mid_batch(const MidJob* __restrict__ jobs) {
     const MidJob& J = jobs[blockIdx.x];   // uniform per workgroup: scalar loads
-    solve_mid_body(J.g, J.rule, nullptr, 0, 0, 1 << 22, 1, J.cap);
+    solve_mid_body<NT>(J.g, J.rule, nullptr, 0, 0, 1 << 22, 1, J.cap);
 }
 
 // The reduced-cost half alone (overlapped graphs: the next pivot's pricing waits for this half only, see build_graph)
@@ -2032,8 +2037,21 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
     if ((e = hipEventRecord(ev[0], s)) != hipSuccess) return bail("hipEventRecord", e);
     if (!small_jobs.empty())
         hipLaunchKernelGGL(k_solve_small_batch, dim3((unsigned)small_jobs.size()), dim3(kSmallThreads), lds, s, (const SmallJob*)d_small);
-    if (!mid_jobs.empty())
-        hipLaunchKernelGGL(k_solve_mid_batch, dim3((unsigned)mid_jobs.size()), dim3(kPivotThreads), 0, s, (const MidJob*)d_mid);
+    {
+        // Two narrow workgroups per CU pay when there are more instances than CUs and the per-pivot passes are short
+        // (measured, 512 instances: 1 024 nodes 1.4x, 4 096 nodes 1.06x; with <= 256 instances a narrow workgroup only has
+        // half the lanes: 0.75-0.9x).  MCF_BATCH_THREADS = 512 / 1024 forces either.
+        const char* bt = std::getenv("MCF_BATCH_THREADS");
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h0->device);
+        int32_t max_nodes = 0;
+        for (const MidJob& J : mid_jobs) if (J.g.n_nodes > max_nodes) max_nodes = J.g.n_nodes;
+        const bool wide = bt ? std::atoi(bt) == 1024 : !((int)mid_jobs.size() > cus && max_nodes <= 4096);
+        if (!mid_jobs.empty() && wide)
+            hipLaunchKernelGGL(k_solve_mid_batch<1024>, dim3((unsigned)mid_jobs.size()), dim3(1024), 0, s, (const MidJob*)d_mid);
+        else if (!mid_jobs.empty())
+            hipLaunchKernelGGL(k_solve_mid_batch<512>, dim3((unsigned)mid_jobs.size()), dim3(512), 0, s, (const MidJob*)d_mid);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return bail("mcf_solve_batch launch", e);
     if ((e = hipEventRecord(ev[1], s)) != hipSuccess) return bail("hipEventRecord", e);
     // every control block back in one go (the copies queue up behind the kernels on the same stream)
