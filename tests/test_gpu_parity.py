@@ -1192,8 +1192,10 @@ def test_solve_many_equals_solving_one_by_one(gpu_engine_module):
         nfs.solve_many(problems)
 
 
-def test_batched_persistent_loops_equal_one_by_one(gpu_engine_module):
-    """mcf_solve_batch over persistent-loop handles (state in global memory, one workgroup per instance), mixed with LDS-loop
+@pytest.mark.parametrize("width", ["512", "1024"])
+def test_batched_persistent_loops_equal_one_by_one(gpu_engine_module, monkeypatch, width):
+    """mcf_solve_batch over persistent-loop handles (state in global memory, one workgroup per instance -- of 1 024 threads,
+    or of 512 so that two instances share a CU: the launch picks by count and size, the test forces each), mixed with LDS-loop
     handles in the same call: every instance ends exactly where its own solve ends; candidate-list handles of that path and
     graph-path handles are refused."""
     e = gpu_engine_module
@@ -1201,6 +1203,7 @@ def test_batched_persistent_loops_equal_one_by_one(gpu_engine_module):
     insts += [generators.netgen_style(128, 1024, seed=50 + k) for k in range(4)]
     rules = [k % 2 for k in range(len(insts))]
     single = [_solve(e, inst, rule) for inst, rule in zip(insts, rules)]
+    monkeypatch.setenv("MCF_BATCH_THREADS", width)
     engines = [e.McfEngine(i.n, i.tail, i.head, i.cost, i.cap, i.supply, rule=r, mid_loop=1) for i, r in zip(insts, rules)]
     try:
         assert sorted({eng.stats()["pricing_mode"] for eng in engines}) == [2, 3]
