@@ -6,6 +6,8 @@
 //                   lock step) and updates until the solve ends.
 //   k_solve_mid     <= 1 536 nodes: one persistent workgroup over global (L2-resident) state -- prices a Devex
 //                   block / re-prices the candidate list / sweeps a small arc list, pivots, permutes, patches.
+//                   (both also as k_solve_small_batch / k_solve_mid_batch: MANY independent instances in one launch, one
+//                   persistent workgroup = one CU per instance -- mcf_solve_batch)
 //   otherwise three kernels per pivot on one stream, 64 pivots per captured hipGraph:
 //     k_price_v     Dantzig sweep over 4-BYTE KEY CODES (one per arc, ordering like the violation -state * rc): HBM-bound at
 //                   scale, 13.7 us for 16 M arcs; full-sweep Dantzig handles from 4 M arcs on.
