@@ -6,6 +6,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
+PART=${PART:-ABC}   # A: bench lines + rocprofv3 kernel summaries, B: PMC passes + solve times, C: stamps + windowed profile (one gpurun call each)
+case $PART in *A*)
 timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default exit=$?"
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-hbm-point > $O/bench_default_20steps.json 2> $O/bench_20.err; echo "bench 20 steps exit=$?"
 timeout -k 10 300 python bench.py --workload netgen_1m_16m --no-hbm-point > $O/bench_netgen_1m_16m.json 2> $O/bench_1m.err; echo "bench 1m exit=$?"
@@ -20,6 +22,9 @@ for tag in default netgen_1m_16m netgen_6m_96m; do
   f=$(find $O/prof_$tag -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$tag.csv
   rm -rf $O/prof_$tag
 done
+;; esac
+case $PART in *B*)
+cd /tmp && export TMPDIR=/tmp
 for wl in netgen_1m_16m netgen_6m_96m netgen_8_08a; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     out=$O/pmc_${wl}_$ctr
@@ -32,9 +37,13 @@ for wl in netgen_1m_16m netgen_6m_96m netgen_8_08a; do
 done
 cd $R
 timeout -k 10 500 python scripts/solve_times.py > $O/solve_times.out 2>&1; echo "solve_times exit=$?"; cp gpurun_out/solve_times.json $O/solve_times.json
+;; esac
+case $PART in *C*)
+cd $R
 (cd $R/network_flow_solver_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMCF_STAMPS -o $R/scripts/libmcf_stamps.so mcf_engine.hip) && {
   timeout -k 10 200 python scripts/stamps_pivot.py > $O/stamps_pivot.txt 2>&1; echo "stamps pivot exit=$?"
   timeout -k 10 100 python scripts/stamps_small.py > $O/stamps_small.txt 2>&1; echo "stamps small exit=$?"
 }
 timeout -k 10 600 python scripts/late_phase_profile.py netgen_1m_16m 2 250000 > $O/late_phase_netgen_1m_16m.txt 2>&1; echo "late phase exit=$?"
+;; esac
 ls -la $O
