@@ -105,13 +105,14 @@ def run_pivots(eng, count: int) -> int:
     return restarts
 
 
-def kernel_name(mode: int, rule: int, incremental: bool, bytes_per_arc: float = 9.0) -> str:
+def kernel_name(mode: int, rule: int, incremental: bool, bytes_per_arc: float = 9.0, variant: int = 0) -> str:
+    """The pricing kernel as rocprofv3 names it (profiles/*kernel_stats*.csv)."""
     if mode == 2:
         return "k_solve_small"
     if mode == 3:
         return "k_solve_mid"
-    if mode == 1 and rule != 1 and bytes_per_arc < 5:
-        return f"k_price_v<{'true' if incremental else 'false'}>"          # 4-byte key codes
+    if mode == 1 and rule != 1 and bytes_per_arc < 5:                      # 4-byte key codes; second argument: non-temporal loads
+        return f"k_price_v<{'true' if incremental else 'false'}, {'true' if variant & 2 else 'false'}>"
     if mode == 1:
         return f"k_price_rc<{1 if rule == 1 else 0},false,{'true' if incremental else 'false'}>"
     return f"k_price<{1 if rule == 1 else 0},false>"
@@ -202,7 +203,7 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         # the engine states the compulsory bytes of one launch of ITS sweep kernel (mcf_stats.price_bytes): 4 B per arc
         # for the key-code sweep, 9 B (13 Devex) for the resident-reduced-cost sweep, SURVEY 8d's figure for the gather
         nbytes = float(p1["price_bytes"])
-        kname = kernel_name(mode, rule, incremental, nbytes / max(per_pass, 1))
+        kname = kernel_name(mode, rule, incremental, nbytes / max(per_pass, 1), int(p1.get("sweep_variant", 0)))
         achieved = nbytes / (price_ms * 1e-3) / 1e9
         traffic, src = pmc_traffic(workload, kname)
         survey = (17 if rule == 1 else 13) * per_pass + 8 * (inst.n + 1)

@@ -153,6 +153,8 @@ typedef struct mcf_stats {
     double loop_ms;           /* persistent pivot loops (pricing_mode 2, and 3 outside a graph): summed kernel durations, by HIP
                                  events on the engine's stream around every launch */
     int64_t loop_launches;    /* ... and the number of launches (one launch runs many pivots) */
+    int64_t sweep_variant;    /* which grid sweep the handle launches: bit 0 = 4-byte key codes (k_price_v), bit 1 = non-temporal
+                                 loads (k_price_v<.., true>), bit 2 = incremental (clean workgroups keep their candidate) */
 } mcf_stats;
 
 /* Called from mcf_solve every cb_interval pivots (simplex.py:1143-1154).

@@ -1228,6 +1228,7 @@ struct mcf_handle {
     mcf_options opt{};
     int device = 0;
     hipStream_t stream = nullptr;
+    bool stream_owned = true;   // false: borrowed from the per-device pool (small / mid-size instances)
     // device arrays
     int32_t *d_tail = nullptr, *d_head = nullptr, *d_cost = nullptr, *d_orig = nullptr;
     int8_t* d_state = nullptr;
@@ -1306,6 +1307,51 @@ int usable_devices() {
 
 template <typename T>
 hipError_t dalloc(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T)); }
+
+// Measured on this stack (scripts/bin/hipcost): hipStreamCreate 3.7 ms, hipStreamDestroy 2.5 ms, hipHostFree 0.22 ms --
+// against 4 ms for a whole netgen_8_08a solve and 16 us per instance in a batch (hipMalloc / hipFree: microseconds).
+// Handles of small and mid-size instances therefore borrow a stream from a per-device pool (round robin, never
+// destroyed) and their pinned control-block copy from a pool of slots; large handles keep a stream of their own.
+constexpr int kPoolStreams = 4;
+constexpr int kPooledMaxNodes = 1 << 14;
+constexpr size_t kPinnedSlot = ((sizeof(McfCtx) + 63) & ~(size_t)63) + 64;   // control block + one candidate
+std::mutex g_pool_mu;
+std::vector<hipStream_t> g_pool_streams[64];    // per device
+unsigned g_pool_next[64];
+std::vector<char*> g_pinned_free;               // free slots
+
+hipError_t pool_stream(int device, hipStream_t* out) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    std::vector<hipStream_t>& v = g_pool_streams[device & 63];
+    if ((int)v.size() < kPoolStreams) {
+        hipStream_t s = nullptr;
+        const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        v.push_back(s);
+        *out = s;
+        return hipSuccess;
+    }
+    *out = v[g_pool_next[device & 63]++ % kPoolStreams];
+    return hipSuccess;
+}
+
+hipError_t pinned_take(char** out) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (g_pinned_free.empty()) {
+        constexpr int kSlots = 256;
+        char* block = nullptr;
+        const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&block), kSlots * kPinnedSlot, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        for (int i = kSlots - 1; i >= 0; --i) g_pinned_free.push_back(block + (size_t)i * kPinnedSlot);
+    }
+    *out = g_pinned_free.back();
+    g_pinned_free.pop_back();
+    return hipSuccess;
+}
+void pinned_give(char* slot) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    g_pinned_free.push_back(slot);
+}
 
 int upload_image(mcf_handle* h) {
     const McfHostImage& im = h->im;
@@ -1552,6 +1598,7 @@ int read_ctx(mcf_handle* h, hipStream_t s) {
 int sync_ctx(mcf_handle* h, hipStream_t s) { return (h->ctx_current && !h->external_driver) ? MCF_OK : read_ctx(h, s); }
 
 void free_all(mcf_handle* h) {
+    if (h->stream) (void)hipStreamSynchronize(h->stream);   // (a borrowed stream may still hold this handle's work)
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
@@ -1563,9 +1610,8 @@ void free_all(mcf_handle* h) {
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
     (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_reach); (void)hipFree(h->d_chg); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_dx); (void)hipFree(h->d_full_tab);
     (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj); (void)hipFree(h->d_vkey);
-    if (h->h_ctx) (void)hipHostFree(h->h_ctx);
-    if (h->h_one) (void)hipHostFree(h->h_one);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->h_ctx) pinned_give(reinterpret_cast<char*>(h->h_ctx));   // (h_one lives in the same slot)
+    if (h->stream && h->stream_owned) (void)hipStreamDestroy(h->stream);
 }
 
 }  // namespace
@@ -1642,7 +1688,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         return e == hipErrorOutOfMemory ? MCF_E_ALLOC : MCF_E_HIP;
     };
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    h->stream_owned = n > kPooledMaxNodes;
+    if ((e = h->stream_owned ? hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) : pool_stream(h->device, &h->stream)) != hipSuccess) return fail("hipStreamCreate", e);
     const size_t N = im.n_nodes;
     if ((e = dalloc(&h->d_tail, im.m_pad)) != hipSuccess) return fail("hipMalloc tail", e);
     if ((e = dalloc(&h->d_head, im.m_pad)) != hipSuccess) return fail("hipMalloc head", e);
@@ -1670,8 +1717,12 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     if ((e = hipMemset(h->d_cand, 0xff, kMaxPriceBlocks * sizeof(McfCand))) != hipSuccess) return fail("hipMemset cand", e);
     if ((e = dalloc(&h->d_one, 1)) != hipSuccess) return fail("hipMalloc one", e);
     if ((e = dalloc(&h->d_swept, kMaxPriceBlocks)) != hipSuccess) return fail("hipMalloc swept", e);
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_ctx), sizeof(McfCtx), hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_one), sizeof(McfCand), hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
+    {   // pinned: the control block's host copy and the one-candidate read-back buffer (one pooled slot)
+        char* slot = nullptr;
+        if ((e = pinned_take(&slot)) != hipSuccess) return fail("hipHostMalloc", e);
+        h->h_ctx = reinterpret_cast<McfCtx*>(slot);
+        h->h_one = reinterpret_cast<McfCand*>(slot + ((sizeof(McfCtx) + 63) & ~(size_t)63));
+    }
 
     McfView& v = h->view;
     v.n_nodes = im.n_nodes;
@@ -1831,8 +1882,16 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         if ((e = hipMemcpy(h->d_dirty, &head, offsetof(McfDirty, flag), hipMemcpyHostToDevice)) != hipSuccess) return fail("copy dirty", e);
         v.dirty = h->d_dirty;
     }
-    const int rc = upload_image(h);
+    const int rc = upload_image(h);   // (ends with a synchronisation of h->stream)
     if (rc != MCF_OK) { g_create_error = h->err; free_all(h); delete h; return rc; }
+    // A handle that captures graphs needs a stream nobody else captures on: only the persistent-loop paths that launch
+    // plain kernels keep the borrowed stream.
+    if (!h->stream_owned && !(h->small || (h->mid && opt.rule != MCF_RULE_CANDIDATE_LIST))) {
+        hipStream_t own = nullptr;
+        if ((e = hipStreamCreateWithFlags(&own, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+        h->stream = own;
+        h->stream_owned = true;
+    }
     *out = h;
     return MCF_OK;
 }
@@ -2119,6 +2178,7 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
         h->stats.unbounded_arc = c.unbounded_arc >= 0 ? im.orig[c.unbounded_arc] : -1;
         h->stats.artificial_flow = r.artificial_flow;
         h->stats.pricing_mode = h->small ? 2 : (h->mid ? 3 : (h->rcached ? 1 : 0));
+        h->stats.sweep_variant = ((h->view.vkey && h->opt.rule != MCF_RULE_DEVEX_BLOCK) ? 1 : 0) | (h->view.vkey && h->nt_sweep ? 2 : 0) | (h->view.dirty ? 4 : 0);
         h->stats.cycle_scans = c.scans; h->stats.scan_rounds = c.scan_rounds; {
             h->stats.arcs_swept = c.arcs_priced;  // full sweeps read what they cover ...
             if (h->view.dirty) {                   // ... incremental ones count per pricing workgroup

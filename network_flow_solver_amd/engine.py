@@ -70,7 +70,7 @@ class McfStats(ctypes.Structure):
         ("pivot_launches", ctypes.c_int64), ("apply_launches", ctypes.c_int64), ("price_bytes", ctypes.c_int64),
         ("artificial_flow", ctypes.c_int64), ("pricing_mode", ctypes.c_int64),
         ("cycle_scans", ctypes.c_int64), ("scan_rounds", ctypes.c_int64), ("arcs_swept", ctypes.c_int64),
-        ("loop_ms", ctypes.c_double), ("loop_launches", ctypes.c_int64),
+        ("loop_ms", ctypes.c_double), ("loop_launches", ctypes.c_int64), ("sweep_variant", ctypes.c_int64),
     ]
 
     def as_dict(self) -> dict:
