@@ -1,3 +1,4 @@
+// HIP API costs on the target box (average of 200 calls):  hipcc --offload-arch=gfx950 -O2 -w -o scripts/bin/hipcost scripts/src/hipcost.cpp
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
