@@ -59,7 +59,11 @@ def solve_many(problems, options: SolverOptions | None = None, max_iterations: i
             try:
                 n_nodes = int(problem.supply.shape[0]) if isinstance(problem, SoAProblem) else len(problem.nodes)
                 loop = {"mid_loop": 1} if many and n_nodes <= _BATCH_MAX_NODES else None
-                solvers.append(NetworkSimplex(problem, options=options, engine_options=loop))
+                sv = NetworkSimplex(problem, options=options, engine_options=loop)
+                if loop and sv.pricing_rule == _engine.RULE_CANDIDATE_LIST and sv.engine.stats()["pricing_mode"] == 3:
+                    sv.engine.close()          # a candidate-list solve does not batch: give it the engine's own choice of path
+                    sv = NetworkSimplex(problem, options=options)
+                solvers.append(sv)
             except Exception as exc:  # noqa: BLE001  (InvalidProblemError and friends)
                 if not return_exceptions:
                     raise
