@@ -180,8 +180,8 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
  * The reference solves instances one after the other on one core (benchmarks/runners/run_benchmark.py; its published
  * per-instance figures are all for <= 4 096 nodes): a single such instance can only ever occupy one CU of 256, a batch
  * fills the chip.  Every handle must run as one persistent workgroup -- the fused LDS path (mcf_stats.pricing_mode == 2:
- * about <= 300 nodes / 2 500 arcs) or the persistent loop over global state (pricing_mode == 3, Dantzig / Devex;
- * mcf_options.mid_loop = 1 asks for it at any size) -- on the same device; max_pivots: one budget per handle (< 0: the
+ * about <= 300 nodes / 2 500 arcs) or the persistent loop over global state (pricing_mode == 3; mcf_options.mid_loop = 1
+ * asks for it at any size; a candidate-list loop then does its full sweeps itself) -- on the same device; max_pivots: one budget per handle (< 0: the
  * reference's default) or NULL for the default everywhere; kernel_ms (optional) <- duration of the launches.  Results per
  * handle through mcf_get_result as usual. */
 int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* max_pivots, double* kernel_ms);

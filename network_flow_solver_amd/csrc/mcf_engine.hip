@@ -681,9 +681,50 @@ __device__ __forceinline__ void arm_ctx(McfCtx* c, int64_t cap) {
     if (c->status == MCF_PIVOT_LIMIT && c->pivots < cap) c->status = MCF_RUNNING;
 }
 
+// The candidate-list rule's full sweep done by ONE workgroup (batched persistent loops: no grid to go back to): wave w
+// plays the pricing workgroups w, w + nwaves, ... of the grid sweep -- the same arc sets (workgroup lb * 8 + x: the groups of
+// four arcs g_lo(x) + lb * 256 + [0, 256) + j * nlb * 256 of bucket x, as in k_price_rc / mcf_price_block_of), the same keys,
+// the same tie rule -- and writes the same list, one candidate per (virtual) workgroup.
+template <int NT>
+__device__ __forceinline__ void virtual_list_sweep(const McfView& v, McfCand* list, int nlist) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nlb = nlist / MCF_NUM_BUCKETS;
+    const int8_t* __restrict__ state = v.state;
+    const int64_t* __restrict__ rcache = v.rcache;
+    const int32_t* __restrict__ orig = v.orig;
+    for (int b = wave; b < nlist; b += NT / 64) {
+        const int x = b & (MCF_NUM_BUCKETS - 1), lb = b >> 3;
+        const int64_t lo = v.bucket_off[x], hi = v.bucket_off[x + 1];
+        const int64_t g_lo = lo >> 2, g_hi = (hi + 3) >> 2;
+        int64_t key = 0, best_i = -1;
+        for (int64_t gbase = g_lo + (int64_t)lb * 256; gbase < g_hi; gbase += (int64_t)nlb * 256) {
+            for (int t = lane; t < 256; t += 64) {
+                const int64_t g = gbase + t;
+                if (g >= g_hi) break;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t i = (g << 2) + k;
+                    if (i < lo || i >= hi) continue;
+                    const int32_t s = state[i];
+                    if (s == 0) continue;
+                    const int64_t viol = -(int64_t)s * rcache[i];
+                    if (viol <= 0) continue;
+                    const int64_t kk = mcf_dantzig_key(v, i, viol, s);
+                    if (kk < key) continue;
+                    if (kk > key || best_i < 0 || orig[i] < orig[best_i]) { key = kk; best_i = i; }
+                }
+            }
+        }
+        int64_t arc = best_i >= 0 ? mcf_pack_arc(orig[best_i], best_i) : -1;
+        wave_argmax(key, arc);
+        if (lane == 0) list[b] = McfCand{key, arc};
+    }
+}
+
 template <int NT = kPivotThreads>   // NT: threads of the workgroup (the batched launch also runs narrower workgroups, two per CU)
-__device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, const McfCand* __restrict__ cand,
-                                               int ncand, int fresh, int max_iters, int arm, int64_t cap) {
+__device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, const McfCand* cand,   // (no __restrict__: cand and
+                                               int ncand, int fresh, int max_iters, int arm, int64_t cap,   //  self_list are the same memory)
+                                               McfCand* self_list = nullptr) {   // non-null: the loop sweeps for itself
     __shared__ PivotShared S;
     __shared__ int32_t s_gran[MCF_NUM_BUCKETS][MCF_GRANULES + 1];  // Devex: the granule table (blocks move and resize under the tuner)
     __shared__ int32_t s_lo[MCF_NUM_BUCKETS], s_hi[MCF_NUM_BUCKETS];  // other rules: the whole buckets
@@ -726,7 +767,11 @@ __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, c
         int64_t key = 0, arc = -1, priced = 0;
         if (listing) {
             const bool minor = minor_left > 0;
-            if (!minor && !have_fresh) break;  // a full sweep is due: back to the grid
+            if (!minor && !have_fresh) {
+                if (!self_list) break;  // a full sweep is due: back to the grid
+                virtual_list_sweep<NT>(v, self_list, ncand);
+                __syncthreads();        // the list (global memory, this workgroup's own writes) before anyone reads it
+            }
             have_fresh = false;
             for (int i = threadIdx.x; i < ncand; i += NT) {
                 const McfCand cd = cand[i];
@@ -843,7 +888,8 @@ __global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t 
 struct MidJob {
     McfView g;
     int32_t rule;
-    int32_t pad;
+    int32_t nlist;     // candidate list: its length (= the grid's pricing workgroups) ...
+    McfCand* list;     // ... and where it lives
     int64_t cap;
 };
 
@@ -852,7 +898,7 @@ struct MidJob {
 template <int NT>
 __global__ __launch_bounds__(NT, 4) void k_solve_mid_batch(const MidJob* __restrict__ jobs) {
     const MidJob& J = jobs[blockIdx.x];   // uniform per workgroup: scalar loads
-    solve_mid_body<NT>(J.g, J.rule, nullptr, 0, 0, 1 << 22, 1, J.cap);
+    solve_mid_body<NT>(J.g, J.rule, J.list, J.nlist, 0, 1 << 22, 1, J.cap, J.list);
 }
 
 // The reduced-cost half alone (overlapped graphs: the next pivot's pricing waits for this half only, see build_graph)
@@ -2034,10 +2080,10 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
     for (int32_t i = 0; i < count; ++i) {
         mcf_handle* h = handles[i];
         if (!h) return MCF_E_BAD_ARG;
-        const bool loop = h->small || (h->mid && h->opt.rule != MCF_RULE_CANDIDATE_LIST);
+        const bool loop = h->small || h->mid;
         if (!loop || h->shards != 1 || h->device != h0->device) {
             h0->err = "mcf_solve_batch: every handle must run as ONE persistent workgroup -- mcf_stats.pricing_mode 2 (LDS loop) or 3 "
-                      "(persistent loop, Dantzig / Devex; mcf_options.mid_loop = 1 asks for it at any size) -- on one device";
+                      "(persistent loop; mcf_options.mid_loop = 1 asks for it at any size) -- on one device";
             return MCF_E_STATE;
         }
         for (int32_t j = 0; j < i; ++j)
@@ -2064,7 +2110,7 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
             if (h->small_layout.total > lds) lds = h->small_layout.total;
         } else {
             MidJob J;
-            J.g = h->view; J.rule = h->opt.rule; J.pad = 0; J.cap = cap;
+            J.g = h->view; J.rule = h->opt.rule; J.nlist = h->price_blocks; J.list = h->d_cand; J.cap = cap;
             mid_jobs.push_back(J);
         }
     }

@@ -419,7 +419,7 @@ def dimacs_load(path: str):
 def solve_batch(engines, max_pivots=None) -> float:
     """Solve independent instances side by side: one persistent workgroup per engine, one launch per engine path
     (``mcf_solve_batch``).  Every engine must be on the fused LDS path (``stats()["pricing_mode"] == 2``) or on the persistent
-    loop with Dantzig / Devex pricing (``pricing_mode == 3``; ``mid_loop=1`` asks for it at any size).  ``max_pivots``: None
+    loop (``pricing_mode == 3``; ``mid_loop=1`` asks for it at any size).  ``max_pivots``: None
     (the reference's default budget everywhere), one int, or one int per engine.  Returns the launches' duration in
     milliseconds; results through each engine's ``result()`` as after ``solve()``."""
     engines = list(engines)

@@ -42,8 +42,7 @@ _BATCH_MIN_PROBLEMS = 4
 def solve_many(problems, options: SolverOptions | None = None, max_iterations: int | None = None,
                return_exceptions: bool = False) -> list:
     """Solve independent problems side by side: every problem that can run as ONE persistent workgroup -- the whole instance
-    in a CU's LDS (up to about 300 nodes / 2 500 arcs, any rule) or, with Dantzig / Devex pricing, its state in global
-    memory (up to 16 384 nodes) -- gets one workgroup of one batched launch (``mcf_solve_batch``).  A single such solve can
+    in a CU's LDS (up to about 300 nodes / 2 500 arcs) or its state in global memory (up to 16 384 nodes) -- gets one workgroup of one batched launch (``mcf_solve_batch``).  A single such solve can
     only occupy one of the chip's 256 CUs; a batch fills it (measured: 256 netgen_8_08a-sized solves in 5.4 ms, 256
     netgen_8_12a-sized ones in 0.40 s).  Everything else is solved one after the other.  Each result is what
     ``solve_min_cost_flow`` returns for that problem; ``UnboundedProblemError`` / ``InvalidProblemError`` are raised unless
@@ -59,19 +58,13 @@ def solve_many(problems, options: SolverOptions | None = None, max_iterations: i
             try:
                 n_nodes = int(problem.supply.shape[0]) if isinstance(problem, SoAProblem) else len(problem.nodes)
                 loop = {"mid_loop": 1} if many and n_nodes <= _BATCH_MAX_NODES else None
-                sv = NetworkSimplex(problem, options=options, engine_options=loop)
-                if loop and sv.pricing_rule == _engine.RULE_CANDIDATE_LIST and sv.engine.stats()["pricing_mode"] == 3:
-                    sv.engine.close()          # a candidate-list solve does not batch: give it the engine's own choice of path
-                    sv = NetworkSimplex(problem, options=options)
-                solvers.append(sv)
+                solvers.append(NetworkSimplex(problem, options=options, engine_options=loop))
             except Exception as exc:  # noqa: BLE001  (InvalidProblemError and friends)
                 if not return_exceptions:
                     raise
                 solvers.append(None)
                 out[k] = exc
-        batched = {k for k, sv in enumerate(solvers) if sv is not None and
-                   (sv.engine.stats()["pricing_mode"] == 2 or
-                    (sv.engine.stats()["pricing_mode"] == 3 and sv.pricing_rule != _engine.RULE_CANDIDATE_LIST))}
+        batched = {k for k, sv in enumerate(solvers) if sv is not None and sv.engine.stats()["pricing_mode"] in (2, 3)}
         if batched:
             order = sorted(batched)
             _engine.solve_batch([solvers[k].engine for k in order], [solvers[k].default_budget(max_iterations) for k in order])

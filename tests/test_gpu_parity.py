@@ -1196,12 +1196,12 @@ def test_solve_many_equals_solving_one_by_one(gpu_engine_module):
 def test_batched_persistent_loops_equal_one_by_one(gpu_engine_module, monkeypatch, width):
     """mcf_solve_batch over persistent-loop handles (state in global memory, one workgroup per instance -- of 1 024 threads,
     or of 512 so that two instances share a CU: the launch picks by count and size, the test forces each), mixed with LDS-loop
-    handles in the same call: every instance ends exactly where its own solve ends; candidate-list handles of that path and
+    handles in the same call: every instance ends exactly where its own solve ends (candidate-list handles sweep for themselves inside the loop);
     graph-path handles are refused."""
     e = gpu_engine_module
     insts = [generators.netgen_style((300, 700, 1500, 3000)[k % 4], (300, 700, 1500, 3000)[k % 4] * 8, seed=7 + k) for k in range(12)]
     insts += [generators.netgen_style(128, 1024, seed=50 + k) for k in range(4)]
-    rules = [k % 2 for k in range(len(insts))]
+    rules = [k % 3 for k in range(len(insts))]
     single = [_solve(e, inst, rule) for inst, rule in zip(insts, rules)]
     monkeypatch.setenv("MCF_BATCH_THREADS", width)
     engines = [e.McfEngine(i.n, i.tail, i.head, i.cost, i.cap, i.supply, rule=r, mid_loop=1) for i, r in zip(insts, rules)]
@@ -1218,10 +1218,10 @@ def test_batched_persistent_loops_equal_one_by_one(gpu_engine_module, monkeypatc
             rc, resident = eng.reduced_costs()
             if resident:
                 assert np.array_equal(rc, inst.cost + tree["pi"][inst.tail] - tree["pi"][inst.head])
-        big = insts[3]   # 3 000 nodes: not an LDS-loop handle
-        with e.McfEngine(big.n, big.tail, big.head, big.cost, big.cap, big.supply, rule=2, mid_loop=1) as lister:
+        big = insts[3]   # 3 000 nodes on the kernel-per-phase graph: not one persistent workgroup
+        with e.McfEngine(big.n, big.tail, big.head, big.cost, big.cap, big.supply, rule=0, mid_loop=-1) as grapher:
             with pytest.raises(e.EngineError) as err:
-                e.solve_batch([engines[0], lister])
+                e.solve_batch([engines[0], grapher])
             assert err.value.code == -6
     finally:
         for eng in engines:
@@ -1231,7 +1231,7 @@ def test_batched_persistent_loops_equal_one_by_one(gpu_engine_module, monkeypatc
 @pytest.mark.parametrize("strategy", ["devex", "dantzig", "candidate_list"])
 def test_solve_many_batches_mid_size_problems_too(gpu_engine_module, strategy):
     """solve_many over flat problems of 300 ... 3 000 nodes: Dantzig / Devex problems run as one persistent workgroup each
-    in the batched launch, candidate-list ones one after the other; every result equals the problem's own solve."""
+    in the batched launch (a candidate-list loop sweeps for itself); every result equals the problem's own solve."""
     insts = [generators.netgen_style(n, 8 * n, seed=11 + k) for k, n in enumerate((300, 700, 1500, 3000, 200, 900))]
     problems = [nfs.SoAProblem(i.n, i.tail, i.head, i.cost, i.cap, i.supply) for i in insts]
     opts = nfs.SolverOptions(pricing_strategy=strategy, explicit_pricing_strategy=True)
