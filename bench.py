@@ -407,9 +407,12 @@ def main():
             "roofline": far.get("roofline"), "kernel_ms": far.get("kernel_ms")}
         _instances.clear()
     if default_run:
-        line["batched_point"] = batched_point(rule)
-        # the largest size the reference publishes numbers for, under its default pricing strategy
-        line["batched_point_netgen_8_12a"] = batched_point(1, instances=256, nodes=4096, arcs=32768, label="netgen_8_12a")
+        try:   # secondary points: a failure here must not cost the headline line
+            line["batched_point"] = batched_point(rule)
+            # the largest size the reference publishes numbers for, under its default pricing strategy
+            line["batched_point_netgen_8_12a"] = batched_point(1, instances=256, nodes=4096, arcs=32768, label="netgen_8_12a")
+        except Exception as exc:  # noqa: BLE001
+            line["batched_point_error"] = f"{type(exc).__name__}: {exc}"
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(workload)
         if "hbm_point" in line:

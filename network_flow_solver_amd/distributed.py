@@ -298,7 +298,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
             torch.cuda.synchronize()
             dist.barrier()
 
-        b = measure_batch(rule if rule != 2 else 0, per_rank, 256, 2048, first_seed=1 + rank * per_rank, before=fence, after=fence)
+        b = measure_batch(rule, per_rank, 256, 2048, first_seed=1 + rank * per_rank, before=fence, after=fence)
         agg = torch.tensor([b["wall_s"], float(b["pivots"]), float(b["arcs_priced"]), 1.0 if b["all_optimal"] else 0.0],
                            dtype=torch.float64, device="cuda")
         tmax = agg[:1].clone()
