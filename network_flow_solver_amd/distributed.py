@@ -290,7 +290,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
     if not args.no_hbm_point and workload == "netgen_8_08a" and not strong:
         # The other way this work spreads over GPUs: INDEPENDENT instances sharded across the ranks -- no data-path
         # collective at all; each rank solves its share as one batched launch (one persistent workgroup per instance).
-        from .batching import measure_batch
+        from .batching import BatchRun
 
         per_rank = 1024
 
@@ -298,19 +298,31 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
             torch.cuda.synchronize()
             dist.barrier()
 
-        b = measure_batch(rule, per_rank, 256, 2048, first_seed=1 + rank * per_rank, before=fence, after=fence)
-        agg = torch.tensor([b["wall_s"], float(b["pivots"]), float(b["arcs_priced"]), 1.0 if b["all_optimal"] else 0.0],
-                           dtype=torch.float64, device="cuda")
-        tmax = agg[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        secs = float(tmax.item())
-        line["batched_point"] = {
-            "workload": f"{per_rank * world} independent netgen_8_08a-sized instances (256 nodes / 2048 arcs), {per_rank} per GPU, whole solves",
-            "parallelism": f"instances sharded x{world}, no collective in the data path", "scaling": "weak",
-            "pivots": int(agg[1].item()), "seconds": secs, "pivots_per_sec": float(agg[1].item()) / secs,
-            "value": float(agg[2].item()) / secs, "unit": "arcs/s", "solves_per_sec": per_rank * world / secs,
-            "all_optimal": bool(agg[3].item() == world)}
+        run, err = None, ""
+        try:
+            run = BatchRun(rule, per_rank, 256, 2048, first_seed=1 + rank * per_rank)
+        except Exception as exc:  # noqa: BLE001  (every rank must reach the vote below)
+            err = f"{type(exc).__name__}: {exc}"
+        ready = torch.tensor([1.0 if run is not None else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        if ready.item() == 1.0:
+            b = run.run(before=fence, after=fence)
+            agg = torch.tensor([b["wall_s"], float(b["pivots"]), float(b["arcs_priced"]), 1.0 if b["all_optimal"] else 0.0],
+                               dtype=torch.float64, device="cuda")
+            tmax = agg[:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            secs = float(tmax.item())
+            line["batched_point"] = {
+                "workload": f"{per_rank * world} independent netgen_8_08a-sized instances (256 nodes / 2048 arcs), {per_rank} per GPU, whole solves",
+                "parallelism": f"instances sharded x{world}, no collective in the data path", "scaling": "weak",
+                "pivots": int(agg[1].item()), "seconds": secs, "pivots_per_sec": float(agg[1].item()) / secs,
+                "value": float(agg[2].item()) / secs, "unit": "arcs/s", "solves_per_sec": per_rank * world / secs,
+                "all_optimal": bool(agg[3].item() == world)}
+        else:
+            line["batched_point_error"] = err or "another rank could not create its handles"
+        if run is not None:
+            run.close()
     if rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     dist.barrier()
