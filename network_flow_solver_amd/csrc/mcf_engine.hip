@@ -34,6 +34,7 @@
 // MCF_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
@@ -721,10 +722,13 @@ __device__ __forceinline__ void virtual_list_sweep(const McfView& v, McfCand* li
     }
 }
 
-template <int NT = kPivotThreads>   // NT: threads of the workgroup (the batched launch also runs narrower workgroups, two per CU)
-__device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, const McfCand* cand,   // (no __restrict__: cand and
-                                               int ncand, int fresh, int max_iters, int arm, int64_t cap,   //  self_list are the same memory)
-                                               McfCand* self_list = nullptr) {   // non-null: the loop sweeps for itself
+// NT: threads of the workgroup (the batched launch also runs narrower workgroups, two per CU).  SELF: a candidate-list loop does
+// the list's full sweeps itself (cand is then written as well as read).  A template parameter, not a run-time flag: with the
+// sweep inlined into every instance the loop's register demand went up (spills 9 -> 21 VGPRs, scratch 72 -> 488 B) and
+// every rule lost 30-45 % -- only the kernels that need it carry it.
+template <int NT = kPivotThreads, bool SELF = false>
+__device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, McfCand* cand,
+                                               int ncand, int fresh, int max_iters, int arm, int64_t cap) {
     __shared__ PivotShared S;
     __shared__ int32_t s_gran[MCF_NUM_BUCKETS][MCF_GRANULES + 1];  // Devex: the granule table (blocks move and resize under the tuner)
     __shared__ int32_t s_lo[MCF_NUM_BUCKETS], s_hi[MCF_NUM_BUCKETS];  // other rules: the whole buckets
@@ -768,9 +772,11 @@ __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, c
         if (listing) {
             const bool minor = minor_left > 0;
             if (!minor && !have_fresh) {
-                if (!self_list) break;  // a full sweep is due: back to the grid
-                virtual_list_sweep<NT>(v, self_list, ncand);
-                __syncthreads();        // the list (global memory, this workgroup's own writes) before anyone reads it
+                if constexpr (!SELF) break;  // a full sweep is due: back to the grid
+                else {
+                    virtual_list_sweep<NT>(v, cand, ncand);
+                    __syncthreads();         // the list (global memory, this workgroup's own writes) before anyone reads it
+                }
             }
             have_fresh = false;
             for (int i = threadIdx.x; i < ncand; i += NT) {
@@ -878,8 +884,8 @@ __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, c
 #endif
 }
 
-__global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t rule, const McfCand* __restrict__ cand,
-                                                              int ncand, int fresh, int max_iters, int arm, int64_t cap) {
+__global__ __launch_bounds__(kPivotThreads) void k_solve_mid(McfView g, int32_t rule, McfCand* cand, int ncand, int fresh,
+                                                              int max_iters, int arm, int64_t cap) {
     solve_mid_body(g, rule, cand, ncand, fresh, max_iters, arm, cap);
 }
 
@@ -895,10 +901,10 @@ struct MidJob {
 
 // 4 waves per SIMD (<= 128 VGPRs): one workgroup of 1 024 or TWO of 512 per CU -- the loop is a chain of dependent memory
 // round trips, so a second instance on the CU fills the first one's waiting time (scripts/batch_mid.py, MCF_BATCH_THREADS).
-template <int NT>
+template <int NT, bool SELF>   // SELF: the candidate-list jobs of a batch (their own launch)
 __global__ __launch_bounds__(NT, 4) void k_solve_mid_batch(const MidJob* __restrict__ jobs) {
     const MidJob& J = jobs[blockIdx.x];   // uniform per workgroup: scalar loads
-    solve_mid_body<NT>(J.g, J.rule, J.list, J.nlist, 0, 1 << 22, 1, J.cap, J.list);
+    solve_mid_body<NT, SELF>(J.g, J.rule, J.list, J.nlist, 0, 1 << 22, 1, J.cap);
 }
 
 // The reduced-cost half alone (overlapped graphs: the next pivot's pricing waits for this half only, see build_graph)
@@ -2114,6 +2120,10 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
             mid_jobs.push_back(J);
         }
     }
+    // candidate-list jobs last (their own launch)
+    std::stable_partition(mid_jobs.begin(), mid_jobs.end(), [](const MidJob& J) { return J.rule != MCF_RULE_CANDIDATE_LIST; });
+    size_t n_listing = 0;
+    for (const MidJob& J : mid_jobs) n_listing += J.rule == MCF_RULE_CANDIDATE_LIST ? 1 : 0;
     SmallJob* d_small = nullptr;
     MidJob* d_mid = nullptr;
     McfCtx* h_all = nullptr;
@@ -2154,10 +2164,14 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
         int32_t max_nodes = 0;
         for (const MidJob& J : mid_jobs) if (J.g.n_nodes > max_nodes) max_nodes = J.g.n_nodes;
         const bool wide = bt ? std::atoi(bt) == 1024 : !((int)mid_jobs.size() > cus && max_nodes <= 4096);
-        if (!mid_jobs.empty() && wide)
-            hipLaunchKernelGGL(k_solve_mid_batch<1024>, dim3((unsigned)mid_jobs.size()), dim3(1024), 0, s, (const MidJob*)d_mid);
-        else if (!mid_jobs.empty())
-            hipLaunchKernelGGL(k_solve_mid_batch<512>, dim3((unsigned)mid_jobs.size()), dim3(512), 0, s, (const MidJob*)d_mid);
+        // the candidate-list jobs sit behind the others in the array (sorted above) and get the kernel that sweeps for itself
+        const unsigned n_plain = (unsigned)(mid_jobs.size() - n_listing), n_list = (unsigned)n_listing;
+        const MidJob* plain = d_mid;
+        const MidJob* lists = d_mid ? d_mid + n_plain : nullptr;
+        if (n_plain && wide) hipLaunchKernelGGL((k_solve_mid_batch<1024, false>), dim3(n_plain), dim3(1024), 0, s, plain);
+        else if (n_plain) hipLaunchKernelGGL((k_solve_mid_batch<512, false>), dim3(n_plain), dim3(512), 0, s, plain);
+        if (n_list && wide) hipLaunchKernelGGL((k_solve_mid_batch<1024, true>), dim3(n_list), dim3(1024), 0, s, lists);
+        else if (n_list) hipLaunchKernelGGL((k_solve_mid_batch<512, true>), dim3(n_list), dim3(512), 0, s, lists);
     }
     if ((e = hipGetLastError()) != hipSuccess) return bail("mcf_solve_batch launch", e);
     if ((e = hipEventRecord(ev[1], s)) != hipSuccess) return bail("hipEventRecord", e);
