@@ -1405,25 +1405,52 @@ void pinned_give(char* slot) {
     g_pinned_free.push_back(slot);
 }
 
+// Host-to-device copies of an image go through a pinned staging buffer (one per host thread) when they fit: a copy from
+// pageable memory costs ~34 us here whatever its size, from pinned memory a few (mcf_create of a small instance: ~15 copies).
+constexpr size_t kStageBytes = (size_t)2 << 20;
+struct Stage {
+    char* base = nullptr;
+    size_t used = 0;
+    bool tried = false;
+};
+thread_local Stage t_stage;
+
+hipError_t h2d(mcf_handle* h, void* dst, const void* src, size_t bytes) {
+    Stage& st = t_stage;
+    if (!st.tried) {
+        st.tried = true;
+        if (hipHostMalloc(reinterpret_cast<void**>(&st.base), kStageBytes, hipHostMallocDefault) != hipSuccess) { st.base = nullptr; (void)hipGetLastError(); }
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (st.base && st.used + need <= kStageBytes) {
+        char* p = st.base + st.used;
+        st.used += need;
+        std::memcpy(p, src, bytes);
+        return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, h->stream);
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
+}
+
 int upload_image(mcf_handle* h) {
     const McfHostImage& im = h->im;
-    HIP_TRY(h, hipMemcpyAsync(h->d_tail, im.tail.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_head, im.head.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_cost, im.cost.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_orig, im.orig.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_state, im.state.data(), im.m_pad, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_weight, im.weight.data(), im.m_pad * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_arcw, im.arcw.data(), im.arcw.size() * sizeof(McfArcW), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_pi, im.pi.data(), im.pi.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_node, im.node.data(), im.node.size() * sizeof(McfNode), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_order0, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_order1, im.order.data(), im.order.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_pos0, im.pos.data(), im.pos.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_pos1, im.pos.data(), im.pos.size() * 4, hipMemcpyHostToDevice, h->stream));
+    t_stage.used = 0;   // (everything staged below is synchronised before this function returns)
+    HIP_TRY(h, h2d(h, h->d_tail, im.tail.data(), im.m_pad * 4));
+    HIP_TRY(h, h2d(h, h->d_head, im.head.data(), im.m_pad * 4));
+    HIP_TRY(h, h2d(h, h->d_cost, im.cost.data(), im.m_pad * 4));
+    HIP_TRY(h, h2d(h, h->d_orig, im.orig.data(), im.m_pad * 4));
+    HIP_TRY(h, h2d(h, h->d_state, im.state.data(), im.m_pad));
+    HIP_TRY(h, h2d(h, h->d_weight, im.weight.data(), im.m_pad * 4));
+    HIP_TRY(h, h2d(h, h->d_arcw, im.arcw.data(), im.arcw.size() * sizeof(McfArcW)));
+    HIP_TRY(h, h2d(h, h->d_pi, im.pi.data(), im.pi.size() * 8));
+    HIP_TRY(h, h2d(h, h->d_node, im.node.data(), im.node.size() * sizeof(McfNode)));
+    HIP_TRY(h, h2d(h, h->d_order0, im.order.data(), im.order.size() * 4));
+    HIP_TRY(h, h2d(h, h->d_order1, im.order.data(), im.order.size() * 4));
+    HIP_TRY(h, h2d(h, h->d_pos0, im.pos.data(), im.pos.size() * 4));
+    HIP_TRY(h, h2d(h, h->d_pos1, im.pos.data(), im.pos.size() * 4));
     std::vector<int32_t> reach;  // (outlives the asynchronous copy: synchronised at the end of this function)
     if (h->d_psz0) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_psz0, im.psize.data(), im.psize.size() * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_psz1, im.psize.data(), im.psize.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, h2d(h, h->d_psz0, im.psize.data(), im.psize.size() * 4));
+        HIP_TRY(h, h2d(h, h->d_psz1, im.psize.data(), im.psize.size() * 4));
         if (h->d_reach) {
             const int64_t nb = ((int64_t)im.n_nodes + MCF_REACH_BLOCK - 1) / MCF_REACH_BLOCK;
             reach.assign((size_t)nb, 0);
@@ -1431,16 +1458,16 @@ int upload_image(mcf_handle* h) {
                 const int32_t end = (int32_t)(j + im.psize[j]);
                 if (end > reach[j >> MCF_REACH_SHIFT]) reach[j >> MCF_REACH_SHIFT] = end;
             }
-            HIP_TRY(h, hipMemcpyAsync(h->d_reach, reach.data(), reach.size() * 4, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, h2d(h, h->d_reach, reach.data(), reach.size() * 4));
         }
     }
     if (h->rcached)
-        HIP_TRY(h, hipMemcpyAsync(h->d_rcache, im.rcache.data(), im.m_pad * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, h2d(h, h->d_rcache, im.rcache.data(), im.m_pad * 8));
     std::vector<int32_t> vk;  // (synchronised before this function returns)
     if (h->d_vkey) {
         vk.assign(im.m_pad, 0);
         for (int64_t e = 0; e < im.m; ++e) vk[e] = mcf_vkey(-(int64_t)im.state[e] * im.rcache[e], h->view.vk_bigm, h->view.vk_half);
-        HIP_TRY(h, hipMemcpyAsync(h->d_vkey, vk.data(), vk.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, h2d(h, h->d_vkey, vk.data(), vk.size() * 4));
     }
     if (h->d_dirty) HIP_TRY(h, hipMemsetAsync(h->d_dirty->flag, 1, sizeof(h->d_dirty->flag), h->stream));  // every block is due (any non-zero word)
     if (h->d_swept) HIP_TRY(h, hipMemsetAsync(h->d_swept, 0, kMaxPriceBlocks * sizeof(int64_t), h->stream));
