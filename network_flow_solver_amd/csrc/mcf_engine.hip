@@ -728,7 +728,7 @@ __device__ __forceinline__ void virtual_list_sweep(const McfView& v, McfCand* li
 // every rule lost 30-45 % -- only the kernels that need it carry it.
 template <int NT = kPivotThreads, bool SELF = false>
 __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, McfCand* cand,
-                                               int ncand, int fresh, int max_iters, int arm, int64_t cap) {
+                                               int ncand, int fresh, int max_iters, int arm, int64_t cap, McfCtx* host_ctx = nullptr) {
     __shared__ PivotShared S;
     __shared__ int32_t s_gran[MCF_NUM_BUCKETS][MCF_GRANULES + 1];  // Devex: the granule table (blocks move and resize under the tuner)
     __shared__ int32_t s_lo[MCF_NUM_BUCKETS], s_hi[MCF_NUM_BUCKETS];  // other rules: the whole buckets
@@ -879,6 +879,7 @@ __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, M
         __syncthreads();
     }
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&S.ctx)[threadIdx.x];
+    if (host_ctx && threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(host_ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&S.ctx)[threadIdx.x];
 #ifdef MCF_STAMPS
     if (threadIdx.x == 0) for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i];
 #endif
@@ -897,6 +898,7 @@ struct MidJob {
     int32_t nlist;     // candidate list: its length (= the grid's pricing workgroups) ...
     McfCand* list;     // ... and where it lives
     int64_t cap;
+    McfCtx* host_ctx;  // pinned: the final control block goes straight to the host
 };
 
 // 4 waves per SIMD (<= 128 VGPRs): one workgroup of 1 024 or TWO of 512 per CU -- the loop is a chain of dependent memory
@@ -904,7 +906,7 @@ struct MidJob {
 template <int NT, bool SELF>   // SELF: the candidate-list jobs of a batch (their own launch)
 __global__ __launch_bounds__(NT, 4) void k_solve_mid_batch(const MidJob* __restrict__ jobs) {
     const MidJob& J = jobs[blockIdx.x];   // uniform per workgroup: scalar loads
-    solve_mid_body<NT, SELF>(J.g, J.rule, J.list, J.nlist, 0, 1 << 22, 1, J.cap);
+    solve_mid_body<NT, SELF>(J.g, J.rule, J.list, J.nlist, 0, 1 << 22, 1, J.cap, J.host_ctx);
 }
 
 // The reduced-cost half alone (overlapped graphs: the next pivot's pricing waits for this half only, see build_graph)
@@ -1021,7 +1023,7 @@ __device__ __forceinline__ void copy_words(void* dst, const void* src, uint32_t 
 // The whole solve of one LDS-resident instance by one workgroup (k_solve_small: one instance per launch;
 // k_solve_small_batch: one instance per workgroup of the launch)
 __device__ __forceinline__ void solve_small_body(const McfView& g, const SmallLayout& L, int32_t rule,
-                                                 McfCand* __restrict__ list, int64_t cap, char* smem) {
+                                                 McfCand* __restrict__ list, int64_t cap, char* smem, McfCtx* host_ctx) {
 #ifdef MCF_STAMPS
     unsigned long long stamps_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
@@ -1225,6 +1227,8 @@ __device__ __forceinline__ void solve_small_body(const McfView& g, const SmallLa
     copy_words(g.posbuf[0], smem + L.pos0, N * 4u);
     copy_words(g.posbuf[1], smem + L.pos1, N * 4u);
     copy_words(g.ctx, smem + L.ctx, (uint32_t)sizeof(McfCtx));
+    // ... and straight into the host's pinned copy: the host then only waits for the stream, no read-back copy
+    if (host_ctx) copy_words(host_ctx, smem + L.ctx, (uint32_t)sizeof(McfCtx));
     if (listing && threadIdx.x < MCF_NUM_BUCKETS) list[threadIdx.x] = McfCand{s_lk[threadIdx.x], s_la[threadIdx.x]};
 #ifdef MCF_STAMPS
     STAMP(6);
@@ -1237,9 +1241,9 @@ __device__ __forceinline__ void solve_small_body(const McfView& g, const SmallLa
 }
 
 __global__ __launch_bounds__(kSmallThreads) void k_solve_small(McfView g, SmallLayout L, int32_t rule,
-                                                                McfCand* __restrict__ list, int64_t cap) {
+                                                                McfCand* __restrict__ list, int64_t cap, McfCtx* host_ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    solve_small_body(g, L, rule, list, cap, smem);
+    solve_small_body(g, L, rule, list, cap, smem, host_ctx);
 }
 
 // Many independent small instances side by side: workgroup b solves jobs[b] from start to finish in its own CU's LDS.
@@ -1252,12 +1256,13 @@ struct SmallJob {
     int32_t pad;
     McfCand* list;
     int64_t cap;
+    McfCtx* host_ctx;   // pinned: the final control block goes straight to the host
 };
 
 __global__ __launch_bounds__(kSmallThreads) void k_solve_small_batch(const SmallJob* __restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SmallJob& J = jobs[blockIdx.x];   // uniform per workgroup: scalar loads
-    solve_small_body(J.g, J.L, J.rule, J.list, J.cap, smem);
+    solve_small_body(J.g, J.L, J.rule, J.list, J.cap, smem, J.host_ctx);
 }
 
 // ------------------------------------------------------------------ k_ctl: (re)arm the control block
@@ -2056,7 +2061,7 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
             }
             if (h->small)
                 hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(kSmallThreads), h->small_layout.total, h->stream, h->view,
-                                   h->small_layout, h->opt.rule, h->d_cand, cap);
+                                   h->small_layout, h->opt.rule, h->d_cand, cap, h->h_ctx);
             else {
                 // eager launches need not run past the cap (a replayed graph has a fixed length: its surplus slots early-exit)
                 const int64_t left = cap - h->h_ctx->pivots;
@@ -2067,8 +2072,13 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
             }
             if (timed_loop) HIP_TRY(h, hipEventRecord(h->loop_ev[1], h->stream));
             HIP_TRY(h, hipGetLastError());
-            rc = read_ctx(h, h->stream);
-            if (rc) return rc;
+            if (h->small) {   // the kernel wrote the host's pinned copy itself
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                h->ctx_current = true;
+            } else {
+                rc = read_ctx(h, h->stream);
+                if (rc) return rc;
+            }
             if (timed_loop) {
                 float ms = 0;
                 if (hipEventElapsedTime(&ms, h->loop_ev[0], h->loop_ev[1]) == hipSuccess) { h->stats.loop_ms += ms; h->stats.loop_launches += 1; }
@@ -2138,12 +2148,12 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
         const int64_t cap = h->h_ctx->pivots + mp;
         if (h->small) {
             SmallJob J;
-            J.g = h->view; J.L = h->small_layout; J.rule = h->opt.rule; J.pad = 0; J.list = h->d_cand; J.cap = cap;
+            J.g = h->view; J.L = h->small_layout; J.rule = h->opt.rule; J.pad = 0; J.list = h->d_cand; J.cap = cap; J.host_ctx = h->h_ctx;
             small_jobs.push_back(J);
             if (h->small_layout.total > lds) lds = h->small_layout.total;
         } else {
             MidJob J;
-            J.g = h->view; J.rule = h->opt.rule; J.nlist = h->price_blocks; J.list = h->d_cand; J.cap = cap;
+            J.g = h->view; J.rule = h->opt.rule; J.nlist = h->price_blocks; J.list = h->d_cand; J.cap = cap; J.host_ctx = h->h_ctx;
             mid_jobs.push_back(J);
         }
     }
@@ -2153,12 +2163,10 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
     for (const MidJob& J : mid_jobs) n_listing += J.rule == MCF_RULE_CANDIDATE_LIST ? 1 : 0;
     SmallJob* d_small = nullptr;
     MidJob* d_mid = nullptr;
-    McfCtx* h_all = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     auto cleanup = [&]() {
         if (d_small) (void)hipFree(d_small);
         if (d_mid) (void)hipFree(d_mid);
-        if (h_all) (void)hipHostFree(h_all);
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     };
     auto bail = [&](const char* what, hipError_t e) {
@@ -2176,7 +2184,6 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
         if ((e = hipMalloc(reinterpret_cast<void**>(&d_mid), mid_jobs.size() * sizeof(MidJob))) != hipSuccess) return bail("hipMalloc jobs", e);
         if ((e = hipMemcpyAsync(d_mid, mid_jobs.data(), mid_jobs.size() * sizeof(MidJob), hipMemcpyHostToDevice, s)) != hipSuccess) return bail("hipMemcpy jobs", e);
     }
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h_all), (size_t)count * sizeof(McfCtx), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipEventCreate(&ev[0])) != hipSuccess || (e = hipEventCreate(&ev[1])) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventRecord(ev[0], s)) != hipSuccess) return bail("hipEventRecord", e);
     if (!small_jobs.empty())
@@ -2202,9 +2209,7 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
     }
     if ((e = hipGetLastError()) != hipSuccess) return bail("mcf_solve_batch launch", e);
     if ((e = hipEventRecord(ev[1], s)) != hipSuccess) return bail("hipEventRecord", e);
-    // every control block back in one go (the copies queue up behind the kernels on the same stream)
-    for (int32_t i = 0; i < count; ++i)
-        if ((e = hipMemcpyAsync(&h_all[i], handles[i]->d_ctx, sizeof(McfCtx), hipMemcpyDeviceToHost, s)) != hipSuccess) return bail("hipMemcpy ctx", e);
+    // (every workgroup writes its final control block straight into its handle's pinned host copy: nothing to read back)
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail("hipStreamSynchronize", e);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
@@ -2213,7 +2218,6 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
     int ret = MCF_OK;
     for (int32_t i = 0; i < count; ++i) {
         mcf_handle* h = handles[i];
-        *h->h_ctx = h_all[i];
         h->ctx_current = true;
         h->stats.batches += 1;
         h->stats.solve_seconds += secs / count;   // the batch's wall time, shared out
