@@ -19,7 +19,7 @@ from dataclasses import dataclass
 from . import __version__, engine
 from .data import Arc, NetworkProblem, Node, SolverOptions
 from .exceptions import UnboundedProblemError
-from .solver import solve_min_cost_flow
+from .solver import solve_many, solve_min_cost_flow
 
 
 @dataclass
@@ -80,6 +80,29 @@ class Mi355xAdapter:
                                           "has_duals": True, "device": "MI355X (gfx950)"})
         except Exception as exc:  # adapters never raise (base.py:52-54)
             return SolverResult(cls.name, "", "error", None, 0.0, None, error_message=f"{type(exc).__name__}: {exc}")
+
+    @classmethod
+    def solve_many(cls, problems, timeout_s: float = 60.0) -> list:
+        """A whole benchmark group at once (no counterpart in base.py: the reference's runner loops over ``solve``): the
+        problems that fit one workgroup each share one batched launch (``solver.solve_many``).  One ``SolverResult`` per
+        problem, in order; ``solve_time_ms`` is the group's wall time divided by the group's size; never raises."""
+        try:
+            natives = [_as_native(p) for p in problems]
+            start = time.perf_counter()
+            results = solve_many(natives, SolverOptions(), return_exceptions=True)
+            share_ms = (time.perf_counter() - start) * 1e3 / max(len(natives), 1)
+            out = []
+            for r in results:
+                if isinstance(r, UnboundedProblemError):
+                    out.append(SolverResult(cls.name, "", "unbounded", None, share_ms, None, error_message=str(r)))
+                elif isinstance(r, BaseException):
+                    out.append(SolverResult(cls.name, "", "error", None, share_ms, None, error_message=f"{type(r).__name__}: {r}"))
+                else:
+                    out.append(SolverResult(cls.name, "", r.status, r.objective if r.status == "optimal" else None, share_ms,
+                                            r.iterations, metadata={"batched": True, "has_duals": True, "device": "MI355X (gfx950)"}))
+            return out
+        except Exception as exc:  # adapters never raise (base.py:52-54)
+            return [SolverResult(cls.name, "", "error", None, 0.0, None, error_message=f"{type(exc).__name__}: {exc}") for _ in problems]
 
     @classmethod
     def is_available(cls) -> bool:

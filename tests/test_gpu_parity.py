@@ -1242,3 +1242,16 @@ def test_solve_many_batches_mid_size_problems_too(gpu_engine_module, strategy):
         assert np.array_equal(got.flows.array, one.flows.array)
         ref = oracle.solve_soa(inst, "dantzig", reference_order=False)
         assert got.objective == ref["objective"]
+
+
+def test_adapter_solves_a_benchmark_group_at_once(gpu_engine_module):
+    """Mi355xAdapter.solve_many: one SolverResult per problem, equal to what the per-problem ``solve`` reports."""
+    from network_flow_solver_amd.adapter import Mi355xAdapter
+
+    problems = [nfs.build_problem(c["nodes"], c["arcs"], c["directed"], c["tolerance"]) for c in CASES[:16]]
+    group = Mi355xAdapter.solve_many(problems)
+    assert len(group) == 16
+    for problem, got in zip(problems, group):
+        one = Mi355xAdapter.solve(problem)
+        assert (got.status, got.objective, got.iterations) == (one.status, one.objective, one.iterations)
+        assert got.solver_name == "network_solver_mi355x" and got.solve_time_ms >= 0
