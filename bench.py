@@ -204,24 +204,29 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         # for the key-code sweep, 9 B (13 Devex) for the resident-reduced-cost sweep, SURVEY 8d's figure for the gather
         nbytes = float(p1["price_bytes"])
         kname = kernel_name(mode, rule, incremental, nbytes / max(per_pass, 1), int(p1.get("sweep_variant", 0)))
-        achieved = nbytes / (price_ms * 1e-3) / 1e9
+        # The kernel's duration: 50 back-to-back launches of the sweep between two HIP events on the engine's stream, right
+        # after the timed pivots, on the same device state.  (An event PAIR around every single eager launch of the profiled
+        # pass also brackets that launch's dispatch latency, ~3 us: kept as *_event_pairs_in_loop.  rocprofv3's per-kernel
+        # timestamps of the same loop agree with the back-to-back figure: profiles/r02_kernel_stats_bench_*.csv.)
+        achieved = nbytes / (sweep_ms * 1e-3) / 1e9
         traffic, src = pmc_traffic(workload, kname)
         survey = (17 if rule == 1 else 13) * per_pass + 8 * (inst.n + 1)
         out["roofline"] = {
             "kernel": kname, "bound": "hbm", "workload": out["workload"],
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": min(achieved / HBM_PEAK_GBPS, 1.0),
             "traffic": traffic, "traffic_source": src,
-            "traffic_GBps": (traffic / (price_ms * 1e-3) / 1e9) if traffic else None,
-            "traffic_frac_of_peak": (traffic / (price_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-            "bytes_per_launch": int(nbytes), "ms_per_launch": price_ms, "ms_per_launch_back_to_back": sweep_ms,
-            "achieved_back_to_back": nbytes / (sweep_ms * 1e-3) / 1e9,
+            "traffic_GBps": (traffic / (sweep_ms * 1e-3) / 1e9) if traffic else None,
+            "traffic_frac_of_peak": (traffic / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            "bytes_per_launch": int(nbytes), "ms_per_launch": sweep_ms,
+            "ms_per_launch_event_pairs_in_loop": price_ms, "achieved_event_pairs_in_loop": nbytes / (price_ms * 1e-3) / 1e9,
             "working_set_fits_infinity_cache": bool(nbytes < 256 * 2 ** 20),
             "survey_8d": {"bytes_per_launch": int(survey), "ratio_to_kernel_bytes": survey / max(nbytes, 1),
                           "note": "SURVEY 8d prices the gather formulation (13 B/arc + 8 B/node); the resident sweeps move "
                                   "4 B/arc (key codes) or 9 B/arc (reduced cost + state) and leave the rest to k_update -- "
                                   "not a physical rate of this kernel"},
-            "note": "ms_per_launch: HIP events around every pricing launch of the same K pivots (profiled pass, eager "
-                    "launches); back_to_back: 50 launches between two events",
+            "note": "ms_per_launch: 50 launches of the sweep between two HIP events on the engine's stream (kernel duration; agrees "
+                    "with rocprofv3's average for the kernel in the same loop); *_event_pairs_in_loop: one event pair around every "
+                    "eager launch of the profiled pass of the same K pivots, which includes ~3 us of dispatch latency per launch",
         }
     eng.close()
     return out
