@@ -2037,6 +2037,15 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
         batch = batch / per > 2 ? batch / per : 2;
         if (h->opt.rule != MCF_RULE_CANDIDATE_LIST) batch = 1;
     }
+    if (!h->mid && !h->small && h->opt.rule == MCF_RULE_CANDIDATE_LIST) {
+        // The sweep cadence inside a batch is fixed (one sweep per minor_cap + 1 slots, launch_pivot_triplet): a batch that is
+        // not a whole number of such periods leaves the next batch's first sweep slot in front of a list that is still
+        // live, the sweep is skipped and the slots up to the following sweep slot idle (1 M / 16 M: 33 pivots per 64-slot
+        // graph).  Whole periods only: 64 -> 66 slots at period 33, 63 at period 9.
+        const int period = mcf_minor_cap(h->price_blocks) + 1;
+        const int periods = (batch + period / 2) / period;
+        batch = (periods > 0 ? periods : 1) * period;
+    }
     const bool graph = h->opt.use_graph && !h->opt.profile && !h->small && !(h->mid && batch == 1);
     if (graph) { rc = build_graph(h, batch); if (rc) return rc; }
     bool stop = false;
