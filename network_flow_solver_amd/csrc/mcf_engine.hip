@@ -62,7 +62,7 @@ constexpr int64_t kIncrementalMinArcs = (int64_t)1 << 22;  // incremental sweeps
 constexpr int kScanMaxNodes = 1 << 27;  // (with the coarse index the scan's cost no longer grows with the tree: no practical limit)
 constexpr int kApplyThreads = 256;
 constexpr int kMaxPriceBlocks = 2048;  // 8 workgroups per CU on 256 CUs
-constexpr int kMaxApplyBlocks = 512;
+constexpr int kMaxApplyBlocks = 512;   // (1 024 workgroups: +5 % in the first 40 K pivots at 1 M nodes, nothing over the whole solve -- 124.5 s either way; MCF_APPLY_BLOCKS, scripts/ab_apply_blocks.py)
 #ifndef MCF_PRICE_UNROLL
 #define MCF_PRICE_UNROLL 2
 #endif
@@ -1762,7 +1762,9 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         // 8 * k workgroups, one group of k per XCD head bucket (formula shared with the CPU emulation)
         h->price_blocks = mcf_price_blocks(m, h->shards, opt.price_blocks);
         const int64_t ab = ((int64_t)im.n_nodes + kApplyThreads - 1) / kApplyThreads;
-        h->apply_blocks = (int)(ab < kMaxApplyBlocks ? ab : kMaxApplyBlocks);
+        int max_ab = kMaxApplyBlocks;
+        if (const char* ab_env = std::getenv("MCF_APPLY_BLOCKS")) { const int vv = std::atoi(ab_env); if (vv >= 64 && vv <= 4096) max_ab = vv; }   // A/B switch
+        h->apply_blocks = (int)(ab < max_ab ? ab : max_ab);
     }
 
     auto fail = [&](const char* what, hipError_t e) {
