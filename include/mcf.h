@@ -20,14 +20,18 @@
  *   warm start  simplex.py:740-1010, 1491-1532 ..............................  mcf_set_basis
  *   AdaptiveTuner.adapt_block_size  simplex_adaptive.py:98-151 and the
  *       periodic Devex reset  simplex.py:1370-1400 ..........................  inside mcf_solve (MCF_RULE_DEVEX_BLOCK)
- *   specialised pivot strategies  specialized_pivots.py:69-223, 452-527 .....  MCF_RULE_DANTZIG_FULL (row scan),
- *                                                                               mcf_options.forward_first (min-cost scan)
+ *   specialised pivot strategies  specialized_pivots.py:69-424, 452-527 .....  mcf_options.key_mode (+ arc_priority): row scan,
+ *                                                                               min-cost scan, shortest-path / matching
+ *                                                                               preference classes, max-flow capacity merit
+ *   the benchmark runner's loop over instances
+ *       benchmarks/runners/run_benchmark.py (one solve after the other) ......  mcf_solve_batch (one launch, one CU per instance)
  *   parse_dimacs_file  benchmarks/parsers/dimacs.py:77-286 ..................  mcf_dimacs_scan / mcf_dimacs_load
  *
  * Conventions: plain pointers and sizes only; integer return codes (0 = ok, < 0 =
  * MCF_E_*), never exceptions; the caller owns every buffer it passes; the library owns
  * device memory until mcf_destroy; one handle is not thread-safe, distinct handles are
- * independent.  All problem data are integers: the Python shim scales decimal input
+ * independent (handles of small instances share a few pooled streams: their work is
+ * serialised on the device, never mixed up).  All problem data are integers: the Python shim scales decimal input
  * (and applies the reference's lower-bound shift, simplex.py:413-428) before the call.
  *
  * There is NO CPU fallback: every compute entry point fails with MCF_E_NO_DEVICE when no
