@@ -47,6 +47,8 @@ static inline int64_t mcf_double_bits(double x) { int64_t k; __builtin_memcpy(&k
 #define MCF_ATOMIC_MIN32(p, x) atomicMin(reinterpret_cast<int*>(p), (int)(x))
 #define MCF_ATOMIC_MAX32(p, x) atomicMax(reinterpret_cast<int*>(p), (int)(x))
 #define MCF_ATOMIC_ADD32(p, x) atomicAdd(reinterpret_cast<int*>(p), (int)(x))
+#define MCF_ATOMIC_MAX64(p, x) atomicMax(reinterpret_cast<long long*>(p), (long long)(x))
+#define MCF_ATOMIC_OR32(p, x) atomicOr(reinterpret_cast<int*>(p), (int)(x))
 #else
 #define MCF_TEAM_BARRIER() ((void)0)
 #define MCF_ATOMIC_MIN64(p, x) do { if ((int64_t)(x) < *(p)) *(p) = (int64_t)(x); } while (0)
@@ -54,6 +56,8 @@ static inline int64_t mcf_double_bits(double x) { int64_t k; __builtin_memcpy(&k
 #define MCF_ATOMIC_MAX32(p, x) do { if ((int32_t)(x) > *(p)) *(p) = (int32_t)(x); } while (0)
 static inline int32_t mcf_host_fetch_add32(int32_t* p, int32_t x) { const int32_t o = *p; *p = o + x; return o; }
 #define MCF_ATOMIC_ADD32(p, x) mcf_host_fetch_add32((p), (x))
+#define MCF_ATOMIC_MAX64(p, x) do { if ((int64_t)(x) > *(p)) *(p) = (int64_t)(x); } while (0)
+#define MCF_ATOMIC_OR32(p, x) do { *(p) |= (int32_t)(x); } while (0)
 #endif
 
 enum McfStatus : int32_t {
@@ -238,7 +242,28 @@ struct McfCtx {
                                // than the scan's fixed passes while the tree is shallow, e.g. the first pivots of a cold start)
     int64_t scans;             // pivots whose cycle was completed by the scan
     int64_t scan_rounds;       // chunk iterations of those scans
+    // ---- blocked preorder list (McfView::bmeta != nullptr; see "blocked preorder list" below)
+    int32_t arena;             // which tok / psz / ext arena is current
+    int32_t alloc_next;        // physical blocks of the current arena handed out so far (bump allocation; the scan covers [0, alloc_next))
+    int32_t alloc_prev;        // blocks that existed before this pivot (the ones its update has to look at)
+    int32_t alloc_lo;          // first block this pivot's update may fill: two copy blocks, then the blocks of the re-hung subtree
+    int32_t rebuild;           // this pivot's update writes the whole list densely into the other arena (the pool ran out)
+    int32_t t_ins;             // insertion point of the re-hung subtree in OLD logical coordinates
+    int32_t dense_blocks;      // blocks a dense list needs: ceil(n_nodes / block)
+    int64_t rebuilds;          // (diagnostic)
 };
+
+// ---- blocked preorder list: per-block record and the encodings of loc[] / bext[] (see McfView::bmeta)
+struct McfBlkMeta {
+    int32_t base;   // logical position of the block's slot 0 (MCF_BLK_FREE: the block holds nothing)
+    int32_t rrel;   // max over the live slots o of o + size[o]  (may be too high, never too low)
+};
+#define MCF_BLK_FREE 0x3fffffff          // "base" of a block that holds nothing: no position is ever >= it
+#define MCF_LOC_ARENA (1 << 30)          // loc[node] = slot | arena bit
+#define MCF_LOC_SLOT (MCF_LOC_ARENA - 1)
+#define MCF_EXT_FLAG (1 << 24)           // bext: a subtree that starts in the block shrank, rrel is due for re-indexing
+#define MCF_BLK_COPIES 2                 // copy blocks reserved per pivot (a block is cut at most at the hole T2 leaves and at the insertion point)
+#define MCF_HAS_BPL(v) ((v).bmeta[0] != nullptr)
 
 // Raw views the core functions operate on (device pointers in the kernels,
 // host pointers in the emulation build).
@@ -279,7 +304,7 @@ struct McfView {
     const int8_t* prio;     // [m_pad] MCF_KEY_PRIORITY: bit 0 = the arc is preferred as a forward candidate, bit 1 = as a backward one
     int64_t vk_bigm;        // big-M of the instance (level spacing of the code)
     int32_t vk_half;        // half width of a level: violations within +-vk_half of a multiple of big-M are coded exactly
-    int32_t vk_pad;
+    int32_t blk_shift;      // blocked preorder list: log2(slots per physical block), 6 .. 10 (0 with the dense array)
     const int64_t* adj_off; // [n_nodes] CSR over real nodes: entries of node u are adj[adj_off[u] .. adj_off[u+1])
     const int64_t* adj;     // [2m] (other end point << 32) | (engine arc << 1) | (1 when u is the arc's tail)
     // preorder position of every node, double buffered with the same flip as order[]: while the apply
@@ -298,6 +323,19 @@ struct McfView {
     // on the HIGH side (a shrunken subtree not yet re-indexed): that only costs a wasted block visit.
     int32_t* reach;         // [ceil(n_nodes / 64)] or nullptr
     int32_t* chg;           // [n_nodes] scratch: positions whose subtree shrank in this pivot (their blocks are re-indexed by the apply pass)
+    // ---- blocked preorder list (large trees; nullptr = the dense preorder array above).  The logical preorder is the
+    // same, but it lives in physical blocks of 1 << blk_shift slots with a logical base each, so that re-hanging a
+    // subtree costs O(|T2| + block + blocks / lane) instead of a shift of everything between its old and new place:
+    //   order[a], psz[a]   become the two ARENAS of slots (node id / subtree size per slot, size 0 = empty slot);
+    //   posbuf[0]          becomes loc[node] = slot | arena << 30;  posbuf[1] is unused;
+    //   bmeta[k][b]        {base, rrel} of block b: the slot at offset o holds logical position base + o, and
+    //                      base + rrel >= the end of every subtree that starts in the block (the coarse index);
+    //                      double buffered with ctx.cur like the dense arrays (the update reads [cur], writes [cur ^ 1]);
+    //   bext[a][b]         live slot range of block b in arena a: beg | end << 12 (| MCF_EXT_FLAG: re-index rrel).
+    struct McfBlkMeta* bmeta[2];
+    int32_t* bext[2];
+    int32_t blk_cap;        // physical blocks per arena
+    int32_t blk_pad;
     // ---- incremental pricing (nullptr = every sweep prices every block).  A pricing workgroup's best candidate
     // only changes when an arc of its block changes reduced cost or state; the passes that change arcs raise the
     // block's flag, and a full Dantzig sweep (also the candidate-list rule's) skips the blocks whose flag is down.
@@ -313,6 +351,33 @@ struct McfDirty {
     int32_t pad[3];
     int32_t flag[MCF_MAX_PRICE_BLOCKS];  // != 0: the workgroup has to sweep its block again
 };
+
+// ---- blocked preorder list: small accessors
+MCF_HD int32_t mcf_ext_beg(int32_t x) { return x & 0xfff; }
+MCF_HD int32_t mcf_ext_end(int32_t x) { return (x >> 12) & 0xfff; }
+MCF_HD int32_t mcf_ext_make(int32_t beg, int32_t end) { return beg | (end << 12); }
+
+// Preorder position of `node` under the current view, and the slot that holds it (dense array: the position itself).
+MCF_HD int32_t mcf_node_pos(const McfView& v, const McfCtx* c, int32_t node, int32_t* slot) {
+    if (MCF_HAS_BPL(v)) {
+        const int32_t s = v.posbuf[0][node] & MCF_LOC_SLOT;
+        const McfBlkMeta* bm = c->cur ? v.bmeta[1] : v.bmeta[0];
+        *slot = s;
+        return bm[s >> v.blk_shift].base + (s & ((1 << v.blk_shift) - 1));
+    }
+    const int32_t p = (c->cur ? v.posbuf[1] : v.posbuf[0])[node];
+    *slot = p;
+    return p;
+}
+// the slot arrays of the current view: node id per slot, subtree size per slot
+MCF_HD const int32_t* mcf_slot_nodes(const McfView& v, const McfCtx* c) {
+    const int32_t sel = MCF_HAS_BPL(v) ? c->arena : c->cur;
+    return sel ? v.order[1] : v.order[0];
+}
+MCF_HD int32_t* mcf_slot_sizes(const McfView& v, const McfCtx* c) {
+    const int32_t sel = MCF_HAS_BPL(v) ? c->arena : c->cur;
+    return sel ? v.psz[1] : v.psz[0];
+}
 
 // ---- compressed Dantzig keys (McfView::vkey).  Violations cluster around 0, big-M and 2 big-M (an end point that
 // still hangs on its artificial arc carries a potential of +-big-M), so:
@@ -523,11 +588,14 @@ MCF_HD int64_t mcf_minor_key(const McfView& v, int64_t packed_arc) {
 struct McfPaths {
     int32_t *path1, *path2;
     McfNode *rec1, *rec2;
-    int32_t *ppos1, *ppos2;
+    int32_t *ppos1, *ppos2;  // (logical) preorder positions
     int64_t *flow1, *flow2;  // the arcs' flows as read by the hit pass, or null (then the finish pass re-reads them)
+    int32_t *slot1, *slot2;  // the slots that hold them (dense array: the very same arrays as ppos1 / ppos2)
 };
 MCF_HD McfPaths mcf_view_paths(const McfView& v) {
-    return McfPaths{v.path1, v.path2, v.rec1, v.rec2, v.ppos1, v.ppos2, nullptr, nullptr};
+    // blocked list: the slot scratch sits behind the position scratch (ppos arrays of 2 * n_nodes entries)
+    const int32_t off = MCF_HAS_BPL(v) ? v.n_nodes : 0;
+    return McfPaths{v.path1, v.path2, v.rec1, v.rec2, v.ppos1, v.ppos2, nullptr, nullptr, v.ppos1 + off, v.ppos2 + off};
 }
 
 // One-sided ancestor noted by the scan rounds: (preorder position << 1) | side.  (Fetching the node record right
@@ -542,6 +610,7 @@ struct McfCycle {
     int32_t n1, n2;        // path elements recorded so far
     int32_t u, w;          // where the two climbs stand; u == w: that node is the join
     int32_t pu, pw;        // their preorder positions
+    int32_t su, sw;        // ... and the slots that hold them
     McfNode ru, rw;        // their records
     int32_t p0u, p0w;      // positions and records of the entering arc's end points (first / second)
     McfNode r0u, r0w;
@@ -553,11 +622,12 @@ struct McfCycle {
 #define MCF_REACH_BLOCK (1 << MCF_REACH_SHIFT)
 #define MCF_SCAN_BLK_CAP 2048             // flagged coarse blocks one scan can hold (more: the plain rounds take over)
 struct McfScanAcc {
-    int32_t jpos[2];       // preorder position of the deepest common ancestor met so far, -1: none yet
-                           // (one slot per round parity: a round needs a single barrier)
+    int64_t jpos[2];       // deepest common ancestor met so far: (preorder position << 32) | slot, -1: none yet
+                           // (one entry per round parity: a round needs a single barrier)
     int32_t nhits;         // one-sided ancestors noted so far
     int32_t nblk;          // coarse pass: blocks that may hold an ancestor of either end point
     int32_t blk[MCF_SCAN_BLK_CAP];
+    int32_t blkbase[MCF_SCAN_BLK_CAP];   // ... and the logical position of their slot 0
     int32_t jnode;         // the join and its record (fetched while the hit pass runs)
     McfNode join;
     int64_t wr1[16], wr2[16];  // per-wave results of the ratio reduction
@@ -577,6 +647,7 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
         c->prev_lo = c->lo;
         c->prev_hi = c->hi;
         c->pending_flip = 0;
+        if (c->rebuild) { c->arena ^= 1; c->rebuild = 0; }  // ... and, blocked list, the whole list into the other arena
     }
     if (c->pivots >= c->max_pivots) { c->status = MCF_PIVOT_LIMIT; return false; }
 
@@ -634,11 +705,10 @@ MCF_HD void mcf_cycle_init(const McfView& v, McfCycle* cy) {
     const McfCtx* c = v.ctx;
     cy->u = c->pv_first;
     cy->w = c->pv_second;
-    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
     cy->ru = v.node[cy->u];
     cy->rw = v.node[cy->w];
-    cy->pu = pcur[cy->u];
-    cy->pw = pcur[cy->w];
+    cy->pu = mcf_node_pos(v, c, cy->u, &cy->su);
+    cy->pw = mcf_node_pos(v, c, cy->w, &cy->sw);
     cy->r0u = cy->ru; cy->r0w = cy->rw;
     cy->p0u = cy->pu; cy->p0w = cy->pw;
     cy->small = 0;
@@ -661,8 +731,8 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, McfCycle* cy, int32_t budget) {
     // Depth-balanced climb: per round trip every side that is at least as deep as the other moves
     // up one arc (both when they are level), so the walk costs max(d1, d2) dependent loads instead of
     // d1 + d2; both parents' records and both arcs are requested before anything is looked at.
-    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
-    int32_t u = cy->u, w = cy->w, pu = cy->pu, pw = cy->pw;
+    const McfPaths gp = mcf_view_paths(v);
+    int32_t u = cy->u, w = cy->w, pu = cy->pu, pw = cy->pw, su = cy->su, sw = cy->sw;
     McfNode ru = cy->ru, rw = cy->rw;
     int64_t d1 = cy->d1, d2 = cy->d2;
     int32_t k1 = cy->k1, k2 = cy->k2, n1 = cy->n1, n2 = cy->n2;
@@ -670,36 +740,40 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, McfCycle* cy, int32_t budget) {
     while (u != w && trips < budget) {
         const bool step_u = ru.depth >= rw.depth, step_w = rw.depth >= ru.depth;
         McfNode nu = ru, nw = rw;
-        int32_t npu = pu, npw = pw;
+        int32_t npu = pu, npw = pw, nsu = su, nsw = sw;
         McfArcW au = McfArcW{0, 0}, aw = McfArcW{0, 0};
-        if (step_u) { nu = v.node[ru.parent]; npu = pcur[ru.parent]; au = v.arcw[ru.pred >> 1]; }
-        if (step_w) { nw = v.node[rw.parent]; npw = pcur[rw.parent]; aw = v.arcw[rw.pred >> 1]; }
+        if (step_u) { nu = v.node[ru.parent]; npu = mcf_node_pos(v, c, ru.parent, &nsu); au = v.arcw[ru.pred >> 1]; }
+        if (step_w) { nw = v.node[rw.parent]; npw = mcf_node_pos(v, c, rw.parent, &nsw); aw = v.arcw[rw.pred >> 1]; }
         if (step_u) {
             // first side is walked against the flow: an up arc loses flow, a down arc gains
             const int64_t r = (ru.pred & 1) ? au.flow : (au.cap >= MCF_INF ? MCF_INF : au.cap - au.flow);
             if (r < d1) { d1 = r; k1 = n1; }
             v.path1[n1] = u;
             v.rec1[n1] = ru;
+            gp.slot1[n1] = su;   // (before the position: dense array = the same word)
             v.ppos1[n1] = pu;
             ++n1;
             u = ru.parent;
             ru = nu;
             pu = npu;
+            su = nsu;
         }
         if (step_w) {
             const int64_t r = (rw.pred & 1) ? (aw.cap >= MCF_INF ? MCF_INF : aw.cap - aw.flow) : aw.flow;
             if (r <= d2) { d2 = r; k2 = n2; }
             v.path2[n2] = w;
             v.rec2[n2] = rw;
+            gp.slot2[n2] = sw;
             v.ppos2[n2] = pw;
             ++n2;
             w = rw.parent;
             rw = nw;
             pw = npw;
+            sw = nsw;
         }
         if (++trips > v.n_nodes) { c->status = MCF_INTERNAL_ERROR; return false; }  // depths out of sync: never spin
     }
-    cy->u = u; cy->w = w; cy->ru = ru; cy->rw = rw; cy->pu = pu; cy->pw = pw;
+    cy->u = u; cy->w = w; cy->ru = ru; cy->rw = rw; cy->pu = pu; cy->pw = pw; cy->su = su; cy->sw = sw;
     cy->d1 = d1; cy->d2 = d2; cy->k1 = k1; cy->k2 = k2; cy->n1 = n1; cy->n2 = n2;
     return true;
 }
@@ -731,7 +805,7 @@ MCF_HD void mcf_scan_best_merge(McfScanBest* a, int64_t r1, int32_t i1, int64_t 
 
 // lane 0 of the thread-0 section that precedes the scan: reset the accumulators (saves the scan a barrier)
 MCF_HD void mcf_scan_init(McfScanAcc* acc) {
-    acc->jpos[0] = -1; acc->jpos[1] = -1;
+    acc->jpos[0] = -1; acc->jpos[1] = -1;   // (64-bit)
     acc->nhits = 0;
     acc->nblk = 0;
 }
@@ -743,17 +817,24 @@ MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_
                               int32_t lane, int32_t nlanes, McfScanBest* out) {
     int64_t b1r = 0, b2r = 0;
     int32_t b1i = -1, b2i = -1;
+    const bool bpl = MCF_HAS_BPL(v);
+    const McfBlkMeta* bm = v.ctx->cur ? v.bmeta[1] : v.bmeta[0];
+    const int32_t bs = v.blk_shift, bmask = (1 << bs) - 1;
     for (int32_t t = lane; t < nhits; t += nlanes) {
-        int32_t pos_side;
-        if (t < hits_cap) pos_side = hits[t]; else pos_side = spill[t - hits_cap];
-        const int32_t node = ord[pos_side >> 1];
+        int32_t slot_side;
+        if (t < hits_cap) slot_side = hits[t]; else slot_side = spill[t - hits_cap];
+        const int32_t slot = slot_side >> 1;
+        const int32_t node = ord[slot];
+        // blocked list: the logical position from the block's base (independent of the node load: same round trip)
+        const int32_t pos = bpl ? bm[slot >> bs].base + (slot & bmask) : slot;
         const McfNode rec = v.node[node];
         const McfArcW a = v.arcw[rec.pred >> 1];
-        if (!(pos_side & 1)) {
+        if (!(slot_side & 1)) {
             const int32_t idx = base1 + du - rec.depth;
             pb.path1[idx] = node;
             pb.rec1[idx] = rec;
-            pb.ppos1[idx] = pos_side >> 1;
+            pb.slot1[idx] = slot;   // (before the position: with the dense array both are the same word)
+            pb.ppos1[idx] = pos;
             if (pb.flow1) pb.flow1[idx] = a.flow;
             const int64_t r = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
             if (b1i < 0 || r < b1r || (r == b1r && idx < b1i)) { b1r = r; b1i = idx; }
@@ -761,7 +842,8 @@ MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_
             const int32_t idx = base2 + dw - rec.depth;
             pb.path2[idx] = node;
             pb.rec2[idx] = rec;
-            pb.ppos2[idx] = pos_side >> 1;
+            pb.slot2[idx] = slot;
+            pb.ppos2[idx] = pos;
             if (pb.flow2) pb.flow2[idx] = a.flow;
             const int64_t r = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
             if (b2i < 0 || r < b2r || (r == b2r && idx > b2i)) { b2r = r; b2i = idx; }
@@ -776,7 +858,7 @@ MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_
 // global round trip per look-up.  The caller has run mcf_scan_init(acc) before the barrier in front of this call.
 // Four consecutive positions i0 .. i0 + 3 with their subtree sizes: note the ancestors of the node at position pu
 // and / or pw among them (common ancestor -> jpos, one-sided -> hit list).
-MCF_HD void mcf_scan_group(int32_t i0, const int32_t* sz, int32_t pu, int32_t pw, int32_t pmin, int32_t* jpos_slot,
+MCF_HD void mcf_scan_group(int32_t i0, int32_t s0, const int32_t* sz, int32_t pu, int32_t pw, int32_t pmin, int64_t* jpos_slot,
                            McfScanAcc* acc, McfHit* hits, int32_t hits_cap, McfHit* spill) {
     // Cheap reject of the whole group first: a subtree can hold pu or pw only if it reaches past the lower
     // of the two, and almost every position is a small subtree far to the left of both.
@@ -785,14 +867,14 @@ MCF_HD void mcf_scan_group(int32_t i0, const int32_t* sz, int32_t pu, int32_t pw
     zmax = zmax > z23 ? zmax : z23;
     if (i0 + 3 + zmax <= pmin) return;
     for (int e = 0; e < 4; ++e) {
-        const int32_t i = i0 + e;
+        const int32_t i = i0 + e;   // logical position; the slot that holds it is s0 + e
         // i <= p < i + size  <=>  unsigned(p - i) < unsigned(size)   (sizes are positive; 0 marks "no position")
         const bool au = (uint32_t)(pu - i) < (uint32_t)sz[e];
         const bool aw = (uint32_t)(pw - i) < (uint32_t)sz[e];
-        if (au && aw) MCF_ATOMIC_MAX32(jpos_slot, i);
+        if (au && aw) MCF_ATOMIC_MAX64(jpos_slot, ((int64_t)i << 32) | (uint32_t)(s0 + e));
         else if (au || aw) {
             const int32_t slot = MCF_ATOMIC_ADD32(&acc->nhits, 1);
-            const McfHit hrec = (i << 1) | (aw ? 1 : 0);
+            const McfHit hrec = ((s0 + e) << 1) | (aw ? 1 : 0);
             if (slot < hits_cap) hits[slot] = hrec; else spill[slot - hits_cap] = hrec;
         }
     }
@@ -801,95 +883,130 @@ MCF_HD void mcf_scan_group(int32_t i0, const int32_t* sz, int32_t pu, int32_t pw
 MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_cap, McfCycle* cy, McfScanAcc* acc,
                            McfHit* hits, int32_t hits_cap, int32_t lane, int32_t nlanes) {
     McfCtx* c = v.ctx;
-    const int32_t* ord = c->cur ? v.order[1] : v.order[0];
-    const int32_t* psz = c->cur ? v.psz[1] : v.psz[0];
+    const int32_t* ord = mcf_slot_nodes(v, c);
+    const int32_t* psz = mcf_slot_sizes(v, c);
     McfHit* spill = reinterpret_cast<McfHit*>(v.seg);  // scratch the finish pass only fills later; <= n_nodes entries
     const int32_t pu = cy->pu, pw = cy->pw, du = cy->ru.depth, dw = cy->rw.depth;
     const int32_t pmin = pu < pw ? pu : pw, pmax = pu > pw ? pu : pw;
     const int32_t base1 = cy->n1, base2 = cy->n2;
     MCF_PSTAMP(4);
-    int32_t rounds = 0, jpos = -1;
+    int32_t rounds = 0;
+    int64_t jpk = -1;   // (position << 32) | slot of the join
     bool done = false;
-    // ---- coarse pass (trees too large for a round or two of the plain sweep): which blocks of 64 positions can hold
-    // an ancestor of either end point?  One pass over reach[0 .. pmax / 64], then only those blocks are looked at:
-    // two dependent round trips whatever the depth of the tree (the plain sweep needs (pmax - pos[join]) / 16 384).
-    if (v.reach && pmax >= 2 * nlanes * 4 * MCF_SCAN_GROUPS) {
-        const int32_t nb = (pmax >> MCF_REACH_SHIFT) + 1;
-        // four entries per 16-byte load, MCF_SCAN_GROUPS loads in flight per lane: the pass is one memory round trip per
-        // nlanes * 16 entries (a lane-at-a-time loop of dependent 4-byte loads took 30 us at 4 M nodes)
-        for (int32_t base = 0; base < nb; base += nlanes * 4 * MCF_SCAN_GROUPS) {
-            int32_t rr[MCF_SCAN_GROUPS][4];
+    const bool bpl = MCF_HAS_BPL(v);
+    // ---- coarse pass (trees too large for a round or two of the plain sweep): which blocks can hold an ancestor of
+    // either end point?  Dense array: one pass over reach[0 .. pmax / 64]; blocked list: one pass over the {base, rrel}
+    // records of the blocks handed out so far.  Then only those blocks are looked at: two dependent round trips whatever
+    // the depth of the tree (the plain sweep needs (pmax - pos[join]) / 16 384).
+    if (bpl || (v.reach && pmax >= 2 * nlanes * 4 * MCF_SCAN_GROUPS)) {
+        int32_t* const blk_spill = v.chg;   // blocked list: flagged blocks beyond the LDS list, (block, base) pairs
+        if (bpl) {
+            const McfBlkMeta* bm = c->cur ? v.bmeta[1] : v.bmeta[0];
+            const int32_t nb = c->alloc_next;
+            // two records per 16-byte load (bmeta[] is padded to an even number of records)
+            for (int32_t base = 0; base < nb; base += nlanes * 2 * MCF_SCAN_GROUPS) {
+                int32_t rr[MCF_SCAN_GROUPS][4];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-            for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
-                const int32_t b0 = base + (k * nlanes + lane) * 4;
-                rr[k][0] = rr[k][1] = rr[k][2] = rr[k][3] = 0;
-                if (b0 < nb) {   // (reach[] is padded to a multiple of four entries)
+                for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
+                    const int32_t b0 = base + (k * nlanes + lane) * 2;
+                    rr[k][0] = rr[k][2] = MCF_BLK_FREE; rr[k][1] = rr[k][3] = 0;
+                    if (b0 < nb) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                    const int4 q = *reinterpret_cast<const int4*>(v.reach + b0);
-                    rr[k][0] = q.x; rr[k][1] = q.y; rr[k][2] = q.z; rr[k][3] = q.w;
+                        const int4 q = *reinterpret_cast<const int4*>(bm + b0);
+                        rr[k][0] = q.x; rr[k][1] = q.y; rr[k][2] = q.z; rr[k][3] = q.w;
 #else
-                    for (int e = 0; e < 4; ++e) rr[k][e] = v.reach[b0 + e];
+                        rr[k][0] = bm[b0].base; rr[k][1] = bm[b0].rrel; rr[k][2] = bm[b0 + 1].base; rr[k][3] = bm[b0 + 1].rrel;
 #endif
+                    }
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
+                    const int32_t b0 = base + (k * nlanes + lane) * 2;
+                    for (int e = 0; e < 2; ++e) {
+                        const int32_t b = b0 + e, s0 = rr[k][2 * e], r = s0 + rr[k][2 * e + 1];
+                        if (b < nb && ((s0 <= pu && r > pu) || (s0 <= pw && r > pw))) {
+                            const int32_t slot = MCF_ATOMIC_ADD32(&acc->nblk, 1);
+                            if (slot < MCF_SCAN_BLK_CAP) { acc->blk[slot] = b; acc->blkbase[slot] = s0; }
+                            else { blk_spill[2 * (slot - MCF_SCAN_BLK_CAP)] = b; blk_spill[2 * (slot - MCF_SCAN_BLK_CAP) + 1] = s0; }
+                        }
+                    }
                 }
             }
+        } else {
+            const int32_t nb = (pmax >> MCF_REACH_SHIFT) + 1;
+            // four entries per 16-byte load, MCF_SCAN_GROUPS loads in flight per lane: the pass is one memory round trip per
+            // nlanes * 16 entries (a lane-at-a-time loop of dependent 4-byte loads took 30 us at 4 M nodes)
+            for (int32_t base = 0; base < nb; base += nlanes * 4 * MCF_SCAN_GROUPS) {
+                int32_t rr[MCF_SCAN_GROUPS][4];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-            for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
-                const int32_t b0 = base + (k * nlanes + lane) * 4;
-                for (int e = 0; e < 4; ++e) {
-                    const int32_t b = b0 + e, r = rr[k][e], s0 = b << MCF_REACH_SHIFT;
-                    if (b < nb && ((s0 <= pu && r > pu) || (s0 <= pw && r > pw))) {
-                        const int32_t slot = MCF_ATOMIC_ADD32(&acc->nblk, 1);
-                        if (slot < MCF_SCAN_BLK_CAP) acc->blk[slot] = b;
+                for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
+                    const int32_t b0 = base + (k * nlanes + lane) * 4;
+                    rr[k][0] = rr[k][1] = rr[k][2] = rr[k][3] = 0;
+                    if (b0 < nb) {   // (reach[] is padded to a multiple of four entries)
+#if defined(__HIP_DEVICE_COMPILE__)
+                        const int4 q = *reinterpret_cast<const int4*>(v.reach + b0);
+                        rr[k][0] = q.x; rr[k][1] = q.y; rr[k][2] = q.z; rr[k][3] = q.w;
+#else
+                        for (int e = 0; e < 4; ++e) rr[k][e] = v.reach[b0 + e];
+#endif
+                    }
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
+                    const int32_t b0 = base + (k * nlanes + lane) * 4;
+                    for (int e = 0; e < 4; ++e) {
+                        const int32_t b = b0 + e, r = rr[k][e], s0 = b << MCF_REACH_SHIFT;
+                        if (b < nb && ((s0 <= pu && r > pu) || (s0 <= pw && r > pw))) {
+                            const int32_t slot = MCF_ATOMIC_ADD32(&acc->nblk, 1);
+                            if (slot < MCF_SCAN_BLK_CAP) { acc->blk[slot] = b; acc->blkbase[slot] = s0; }
+                        }
                     }
                 }
             }
         }
         MCF_TEAM_BARRIER();
         const int32_t nf = acc->nblk;
-        if (nf <= MCF_SCAN_BLK_CAP) {
-            // groups of 16 lanes take one flagged block each: 16 x four positions (one 16-byte load per lane)
-            const int32_t per = MCF_REACH_BLOCK / 4;                    // lanes per block
+        if (bpl || nf <= MCF_SCAN_BLK_CAP) {
+            // a group of lanes takes one flagged block: four slots (one 16-byte load) per lane
+            const int32_t bshift = bpl ? v.blk_shift : MCF_REACH_SHIFT;
+            const int32_t per = (1 << bshift) / 4;                      // lanes per block
             const int32_t ngroups = nlanes >= per ? nlanes / per : 1;
             const int32_t g = nlanes >= per ? lane / per : 0, sub0 = nlanes >= per ? lane % per : 0;
             const int32_t nsub = nlanes >= per ? 1 : per;              // a team of one lane walks the block itself
             for (int32_t t = g; t < nf; t += ngroups) {
-                const int32_t b = acc->blk[t];
+                int32_t b, lbase;
+                if (t < MCF_SCAN_BLK_CAP) { b = acc->blk[t]; lbase = acc->blkbase[t]; }
+                else { b = blk_spill[2 * (t - MCF_SCAN_BLK_CAP)]; lbase = blk_spill[2 * (t - MCF_SCAN_BLK_CAP) + 1]; }
                 for (int32_t q = 0; q < nsub; ++q) {
-                    const int32_t i0 = (b << MCF_REACH_SHIFT) + (sub0 + q) * 4;
+                    const int32_t s0 = (b << bshift) + (sub0 + q) * 4;   // slots
+                    const int32_t i0 = lbase + (sub0 + q) * 4;           // their logical positions
                     int32_t sz[4];
 #if defined(__HIP_DEVICE_COMPILE__)
-                    const int4 w4 = *reinterpret_cast<const int4*>(psz + i0);
+                    const int4 w4 = *reinterpret_cast<const int4*>(psz + s0);
                     sz[0] = w4.x; sz[1] = w4.y; sz[2] = w4.z; sz[3] = w4.w;
 #else
-                    for (int e = 0; e < 4; ++e) sz[e] = psz[i0 + e];
+                    for (int e = 0; e < 4; ++e) sz[e] = psz[s0 + e];
 #endif
-                    mcf_scan_group(i0, sz, pu, pw, pmin, &acc->jpos[0], acc, hits, hits_cap, spill);
+                    mcf_scan_group(i0, s0, sz, pu, pw, pmin, &acc->jpos[0], acc, hits, hits_cap, spill);
                 }
             }
             MCF_TEAM_BARRIER();
-            jpos = acc->jpos[0];
+            jpk = acc->jpos[0];
             rounds = 2;
             done = true;
-#if defined(MCF_DEBUG_SCAN) && !defined(__HIP_DEVICE_COMPILE__)
-            {
-                int32_t cnt = 0, jj = -1;
-                for (int32_t i = 0; i <= pmax; ++i) {
-                    const bool au = (uint32_t)(pu - i) < (uint32_t)psz[i], aw = (uint32_t)(pw - i) < (uint32_t)psz[i];
-                    if (au && aw) jj = i; else if (au || aw) ++cnt;
-                    if ((au || aw) && !(v.reach[i >> 6] > (au ? pu : pw))) std::fprintf(stderr, "reach too low: pos %d size %d block %d reach %d pu %d pw %d\n", i, psz[i], i >> 6, v.reach[i >> 6], pu, pw);
-                }
-                if (cnt != acc->nhits || jj != jpos) std::fprintf(stderr, "scan mismatch: hits %d vs %d, join %d vs %d (pu %d pw %d nf %d pivots %lld)\n", acc->nhits, cnt, jpos, jj, pu, pw, nf, (long long)c->pivots);
-            }
-#endif
         }
-        // (more flagged blocks than the list holds: the plain rounds below redo the search; the hit list is still empty
-        //  because the fine pass did not run)
+        // (dense array, more flagged blocks than the list holds: the plain rounds below redo the search; the hit list is
+        //  still empty because the fine pass did not run)
     }
-    // ---- plain rounds: groups of four positions, aligned; psz[] is padded so that the group holding max(pu, pw) can be read whole
+    // ---- plain rounds (dense array): groups of four positions, aligned; psz[] is padded so that the group holding max(pu, pw) can be read whole
     int32_t top = ((pmax + 1) + 3) & ~3;  // exclusive
     int32_t par = 0;
     while (!done) {
@@ -918,24 +1035,25 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
         for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
             const int32_t slice = lo + k * nlanes * 4;
             if (slice + nlanes * 4 <= 0) continue;
-            mcf_scan_group(slice + lane * 4, sz[k], pu, pw, pmin, &acc->jpos[par], acc, hits, hits_cap, spill);
+            mcf_scan_group(slice + lane * 4, slice + lane * 4, sz[k], pu, pw, pmin, &acc->jpos[par], acc, hits, hits_cap, spill);
         }
         MCF_TEAM_BARRIER();
         // the next round's atomics go to the other slot: nobody can overtake a lane still reading this one
-        jpos = acc->jpos[par];
+        jpk = acc->jpos[par];
         par ^= 1;
         ++rounds;
-        if (jpos >= 0 || lo <= 0) break;
+        if (jpk >= 0 || lo <= 0) break;
         top = lo;
     }
-    if (jpos < 0) {  // position 0 is the root, a common ancestor: cannot happen
+    const int32_t jslot = jpk < 0 ? -1 : (int32_t)(jpk & 0xffffffff);
+    if (jslot < 0) {  // position 0 is the root, a common ancestor: cannot happen
         if (lane == 0) c->status = MCF_INTERNAL_ERROR;
         return;
     }
     MCF_PSTAMP(5);
     const int32_t nhits = acc->nhits;  // final: every append precedes the last barrier
     if (lane == nlanes - 1) {  // the join's record rides along with the hit pass (this lane is the last to get a hit)
-        const int32_t jn = ord[jpos];
+        const int32_t jn = ord[jslot];
         acc->jnode = jn;
         acc->join = v.node[jn];
     }
@@ -1095,8 +1213,247 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycl
     c->apply = 1;
     c->pending_flip = 1;
     c->subtree_nodes += S;
-    c->nodes_moved += c->hi - c->lo;
     c->stage = 2;
+    if (MCF_HAS_BPL(v)) {
+        // blocked list: T2 goes into fresh blocks (dense-packed), in front of them two blocks for what has to be cut off
+        // existing blocks; nothing else moves.  The pool is a bump allocator: when it runs out, this pivot's update writes
+        // the WHOLE list densely into the other arena instead (every position is then rewritten once).
+        c->t_ins = t;
+        c->nchg = 0;   // (shrunken subtrees are flagged in bext[], not listed)
+        const int32_t need = MCF_BLK_COPIES + ((S + (1 << v.blk_shift) - 1) >> v.blk_shift);
+        c->alloc_prev = c->alloc_next;
+        if (c->alloc_next + need > v.blk_cap) {
+            c->rebuild = 1;
+            c->rebuilds += 1;
+            c->alloc_lo = 0;
+            c->alloc_next = c->dense_blocks;
+            c->nodes_moved += v.n_nodes;
+        } else {
+            c->rebuild = 0;
+            c->alloc_lo = c->alloc_next;
+            c->alloc_next += need;
+            c->nodes_moved += S;   // (+ the cut-off runs, counted by the update pass)
+        }
+    } else {
+        c->nodes_moved += c->hi - c->lo;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Blocked preorder list: the tree update in O(|T2| + block) element moves.
+//
+// The LOGICAL preorder (what positions, subtree intervals, segments and the insertion point t are expressed in) is
+// exactly the dense array's.  Physically the list lives in blocks of B = 1 << blk_shift slots; block b holds the
+// logical positions base[b] + [beg, end) in its slots [beg, end).  A basis swap takes T2 = [a0, a0 + S) out and puts it
+// back (re-rooted: the segment table) in front of old position t; every other position p moves by
+//     shift(p) = +S for t <= p < a0,   -S for a0 + S <= p < t,   0 otherwise.
+// Per block that is pure interval arithmetic on [L0, L1) = base + [beg, end):
+//   * no element of T2 inside and t not strictly inside: the whole block lies in one zone -> base += shift, nothing moves;
+//   * otherwise the survivors form at most three runs (cut at the hole T2 leaves and at t).  The first run stays where
+//     it is (new base, new [beg, end)); a run right of the cut at t goes to copy block alloc_lo, a run right of the
+//     hole to copy block alloc_lo + 1 (each can only happen in one block of the whole list);
+//   * T2's elements go, dense-packed, to blocks alloc_lo + 2 ...: new logical position j -> slot (j - t2_new).
+// Blocks are never refilled (bump allocation); when the pool runs out the update writes the whole list densely into the
+// other arena (ctx.rebuild).  Freed blocks keep base = MCF_BLK_FREE, empty slots size 0: the cycle scan skips both.
+// ---------------------------------------------------------------------------
+MCF_HD int32_t mcf_bpl_shift(const McfCtx& c, int32_t p) {
+    const int32_t a0 = c.t2_old, S = c.t2_size, t = c.t_ins;
+    if (t <= a0) return (p >= t && p < a0) ? S : 0;
+    return (p >= a0 + S && p < t) ? -S : 0;
+}
+
+struct McfBlkPlan {
+    int32_t touched;            // 0: the block keeps its slots, only the base moves (nbase)
+    int32_t nbase;              // new base of the block (MCF_BLK_FREE: nothing stays)
+    int32_t r0lo, r0hi;         // logical interval (old coordinates) that stays in the block
+    int32_t ilo[2], ihi[2];     // intervals cut off: [0] -> copy block alloc_lo (right of t), [1] -> alloc_lo + 1 (right of the hole)
+};
+
+MCF_HD McfBlkPlan mcf_bpl_plan(const McfCtx& c, int32_t base, int32_t L0, int32_t L1) {
+    McfBlkPlan P;
+    const int32_t a0 = c.t2_old, S = c.t2_size, t = c.t_ins;
+    P.ilo[0] = P.ihi[0] = P.ilo[1] = P.ihi[1] = 0;
+    const bool hit_t2 = L0 < a0 + S && L1 > a0;
+    const bool cut_t = L0 < t && t < L1;
+    if (L1 <= L0) { P.touched = 0; P.nbase = MCF_BLK_FREE; P.r0lo = P.r0hi = 0; return P; }
+    if (!hit_t2 && !cut_t) {
+        P.touched = 0; P.nbase = base + mcf_bpl_shift(c, L0); P.r0lo = L0; P.r0hi = L1;
+        return P;
+    }
+    P.touched = 1;
+    // survivors: A = [L0, min(L1, a0)) and Bv = [max(L0, a0 + S), L1); t cuts one of them strictly inside
+    int32_t lo[3], hi[3], kind[3];   // kind: what lies to the left of the interval -- 0 the cut at t, 1 the hole
+    const int32_t Ahi = L1 < a0 ? L1 : a0, Blo = L0 > a0 + S ? L0 : a0 + S;
+    if (t <= a0) {
+        lo[0] = L0; hi[0] = t < Ahi ? t : Ahi; kind[0] = 0;
+        lo[1] = L0 > t ? L0 : t; hi[1] = Ahi; kind[1] = 0;
+        lo[2] = Blo; hi[2] = L1; kind[2] = 1;
+    } else {
+        lo[0] = L0; hi[0] = Ahi; kind[0] = 0;
+        lo[1] = Blo; hi[1] = t < L1 ? t : L1; kind[1] = 1;
+        lo[2] = Blo > t ? Blo : t; hi[2] = L1; kind[2] = 0;
+    }
+    bool have0 = false;
+    P.r0lo = P.r0hi = 0;
+    int32_t prev_hi = -1;
+    for (int q = 0; q < 3; ++q) {
+        if (hi[q] <= lo[q]) continue;
+        if (!have0) { have0 = true; P.r0lo = lo[q]; P.r0hi = hi[q]; prev_hi = hi[q]; continue; }
+        // a later run: cut off by t when it directly follows the previous run (no hole between), else by the hole
+        const int32_t kd = (lo[q] == prev_hi && kind[q] == 0) ? 0 : 1;
+        P.ilo[kd] = lo[q]; P.ihi[kd] = hi[q];
+        prev_hi = hi[q];
+    }
+    P.nbase = have0 ? base + mcf_bpl_shift(c, P.r0lo) : MCF_BLK_FREE;
+    return P;
+}
+
+// Old logical position i inside T2 -> its new logical position (and the depth change of its piece).  The segment table is
+// sorted by destination; by SOURCE the order is: the left pieces from the outermost stem node inwards (seg[2k-1], seg[2k-3],
+// ..., seg[1]), the innermost block seg[0], then the right pieces outwards (seg[2], seg[4], ..., seg[2k]).  Empty pieces
+// share their source with the next one: the LAST entry whose source is <= i is the one that holds i.
+MCF_HD int32_t mcf_bpl_seg_at(int32_t r, int32_t k) { return r < k ? 2 * (k - r) - 1 : (r == k ? 0 : 2 * (r - k)); }
+MCF_HD int32_t mcf_bpl_new_pos(const McfCtx& c, const McfSeg* seg, int32_t i, int32_t* ddepth) {
+    const int32_t k = (c.nseg - 1) >> 1;
+    int32_t lo = 0, hi = c.nseg - 1;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (seg[mcf_bpl_seg_at(mid, k)].src <= i) lo = mid; else hi = mid - 1;
+    }
+    const McfSeg sg = seg[mcf_bpl_seg_at(lo, k)];
+    *ddepth = sg.ddepth;
+    return sg.dst + (i - sg.src);
+}
+
+// End of the finish pass (all lanes): the records of the blocks this pivot's update will fill, in the meta copy the update
+// writes (bmeta[cur ^ 1]) and in the extents of the arena it writes to.  The update's pushes then only raise rrel.
+MCF_HD void mcf_bpl_prepare(const McfView& v, const McfCtx& c, int32_t lane, int32_t nlanes) {
+    if (c.stage != 2) return;
+    McfBlkMeta* bn = c.cur ? v.bmeta[0] : v.bmeta[1];
+    const int32_t bs = v.blk_shift, B = 1 << bs;
+    if (c.rebuild) {
+        int32_t* xn = c.arena ? v.bext[0] : v.bext[1];   // the OTHER arena
+        const int32_t nd = c.dense_blocks;
+        for (int32_t b = lane; b < nd; b += nlanes) {
+            const int32_t left = v.n_nodes - (b << bs);
+            bn[b] = McfBlkMeta{b << bs, 0};
+            xn[b] = mcf_ext_make(0, left < B ? left : B);
+        }
+        return;
+    }
+    int32_t* xa = c.arena ? v.bext[1] : v.bext[0];
+    const int32_t first = c.alloc_lo, S = c.t2_size;
+    const int32_t nt2 = (S + B - 1) >> bs;
+    for (int32_t q = lane; q < MCF_BLK_COPIES + nt2; q += nlanes) {
+        const int32_t b = first + q;
+        if (q < MCF_BLK_COPIES) { bn[b] = McfBlkMeta{MCF_BLK_FREE, 0}; xa[b] = 0; }
+        else {
+            const int32_t o = (q - MCF_BLK_COPIES) << bs;
+            bn[b] = McfBlkMeta{c.t2_new + o, 0};
+            xa[b] = mcf_ext_make(0, S - o < B ? S - o : B);
+        }
+    }
+}
+
+// One slot of a block the update has to take apart (host: scalar loop; device: one lane per slot).  `p` = old logical
+// position, `nd` / `z` = node and size in the slot.  Returns what stays in the block as o + z (0: nothing), for the
+// block's new rrel.  `cnt` counts elements copied to the cut-off blocks (diagnostic).
+struct McfBplOut { int32_t keep_reach; int32_t copy_reach[2]; int32_t moved; };
+MCF_HD void mcf_bpl_slot(const McfView& v, const McfCtx& c, const McfBlkPlan& P, int32_t slot, int32_t p, int32_t nd, int32_t z,
+                         McfBplOut* out) {
+    const int32_t bs = v.blk_shift, bmask = (1 << bs) - 1;
+    const int32_t a0 = c.t2_old, S = c.t2_size;
+    int32_t* const tok_old = c.arena ? v.order[1] : v.order[0];
+    int32_t* const psz_old = c.arena ? v.psz[1] : v.psz[0];
+    int32_t* const tok_new = c.rebuild ? (c.arena ? v.order[0] : v.order[1]) : tok_old;
+    int32_t* const psz_new = c.rebuild ? (c.arena ? v.psz[0] : v.psz[1]) : psz_old;
+    const int32_t arena_new = (c.rebuild ? (c.arena ^ 1) : c.arena) ? MCF_LOC_ARENA : 0;
+    McfBlkMeta* const bn = c.cur ? v.bmeta[0] : v.bmeta[1];
+    out->keep_reach = 0; out->copy_reach[0] = 0; out->copy_reach[1] = 0; out->moved = 0;
+    const bool in_t2 = p >= a0 && p < a0 + S;
+    int32_t dslot = -1;
+    if (in_t2) {
+        int32_t dd;
+        const int32_t j = mcf_bpl_new_pos(c, v.seg, p, &dd);
+        v.pi[nd] += c.sigma;
+        if (dd) v.node[nd].depth += dd;
+        dslot = c.rebuild ? j : ((c.alloc_lo + MCF_BLK_COPIES) << bs) + (j - c.t2_new);
+        MCF_ATOMIC_MAX32(&bn[dslot >> bs].rrel, (dslot & bmask) + z);
+    } else if (c.rebuild) {
+        dslot = p + mcf_bpl_shift(c, p);
+        MCF_ATOMIC_MAX32(&bn[dslot >> bs].rrel, (dslot & bmask) + z);
+    } else if (p >= P.r0lo && p < P.r0hi) {
+        out->keep_reach = (slot & bmask) + z;
+        return;
+    } else {
+        const int kd = (p >= P.ilo[0] && p < P.ihi[0]) ? 0 : 1;
+        const int32_t o = p - P.ilo[kd];
+        dslot = ((c.alloc_lo + kd) << bs) + o;
+        out->copy_reach[kd] = o + z;
+        out->moved = 1;
+    }
+    tok_new[dslot] = nd;
+    psz_new[dslot] = z;
+    psz_old[slot] = 0;                       // the old slot is empty from now on (size 0: the scan skips it)
+    v.posbuf[0][nd] = dslot | arena_new;
+    (void)tok_old;
+}
+
+// Is `node` (a neighbour of a T2 node) inside T2?  Asked by the reduced-cost patch while other lanes may be moving it:
+// loc[] is one word, and a slot in a block this pivot handed out says what the node is (T2's blocks hold T2, the copy
+// blocks do not); an old slot gives the old position, tested against T2's old interval.
+MCF_HD bool mcf_bpl_in_t2(const McfView& v, const McfCtx& c, int32_t node) {
+    const int32_t lw = v.posbuf[0][node];
+    const int32_t sl = lw & MCF_LOC_SLOT, bs = v.blk_shift;
+    if (c.rebuild) {
+        if (((lw & MCF_LOC_ARENA) != 0) != (c.arena != 0)) return sl >= c.t2_new && sl < c.t2_new + c.t2_size;   // moved: dense, slot = new position
+    } else if ((sl >> bs) >= c.alloc_lo) {
+        return (sl >> bs) >= c.alloc_lo + MCF_BLK_COPIES;
+    }
+    const McfBlkMeta* bm = c.cur ? v.bmeta[1] : v.bmeta[0];
+    const int32_t p = bm[sl >> bs].base + (sl & ((1 << bs) - 1));
+    return p >= c.t2_old && p < c.t2_old + c.t2_size;
+}
+
+// The whole update of one pivot, scalar (CPU emulation; the kernels run the same per-block / per-slot functions with one
+// lane per block, then one lane per slot of the blocks that have to be taken apart).
+MCF_HD void mcf_bpl_update_seq(const McfView& v, const McfCtx& c) {
+    const int32_t bs = v.blk_shift, B = 1 << bs;
+    const McfBlkMeta* bm = c.cur ? v.bmeta[1] : v.bmeta[0];
+    McfBlkMeta* bn = c.cur ? v.bmeta[0] : v.bmeta[1];
+    int32_t* xa = c.arena ? v.bext[1] : v.bext[0];
+    const int32_t* tok = c.arena ? v.order[1] : v.order[0];
+    const int32_t* psz = c.arena ? v.psz[1] : v.psz[0];
+    const int32_t nold = c.alloc_prev;   // blocks that existed before this pivot
+    for (int32_t b = 0; b < nold; ++b) {
+        const McfBlkMeta m = bm[b];
+        const int32_t x = xa[b], beg = mcf_ext_beg(x), end = mcf_ext_end(x);
+        if (m.base == MCF_BLK_FREE || end <= beg) { if (!c.rebuild) bn[b] = McfBlkMeta{MCF_BLK_FREE, 0}; continue; }
+        const McfBlkPlan P = mcf_bpl_plan(c, m.base, m.base + beg, m.base + end);
+        if (!c.rebuild && !P.touched && !(x & MCF_EXT_FLAG)) { bn[b] = McfBlkMeta{P.nbase, m.rrel}; continue; }
+        int32_t keep = 0, cr[2] = {0, 0}, moved = 0;
+        for (int32_t o = beg; o < end; ++o) {
+            const int32_t slot = (b << bs) + o;
+            McfBplOut r;
+            if (!c.rebuild && !P.touched) { r.keep_reach = o + psz[slot]; r.copy_reach[0] = r.copy_reach[1] = 0; r.moved = 0; }   // re-index only
+            else mcf_bpl_slot(v, c, P, slot, m.base + o, tok[slot], psz[slot], &r);
+            if (r.keep_reach > keep) keep = r.keep_reach;
+            if (r.copy_reach[0] > cr[0]) cr[0] = r.copy_reach[0];
+            if (r.copy_reach[1] > cr[1]) cr[1] = r.copy_reach[1];
+            moved += r.moved;
+        }
+        if (c.rebuild) continue;   // (the old arena is left empty; its records die with the flip)
+        bn[b] = McfBlkMeta{P.nbase, keep};
+        xa[b] = P.nbase == MCF_BLK_FREE ? 0 : mcf_ext_make(P.r0lo - m.base, P.r0hi - m.base);
+        for (int kd = 0; kd < 2; ++kd) {
+            if (P.ihi[kd] <= P.ilo[kd]) continue;
+            const int32_t cb = c.alloc_lo + kd;
+            bn[cb] = McfBlkMeta{P.ilo[kd] + mcf_bpl_shift(c, P.ilo[kd]), cr[kd]};
+            xa[cb] = mcf_ext_make(0, P.ihi[kd] - P.ilo[kd]);
+        }
+        v.ctx->nodes_moved += moved;
+    }
+    (void)B;
 }
 
 // The whole cycle search + decision for single-threaded callers (CPU emulation): climb within the
@@ -1173,9 +1530,22 @@ MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane,
     // with this value -- by the apply pass, which reads psz[cur] and overwrites psz[cur ^ 1].
     const int32_t* spos = result == 1 ? pp.ppos1 : pp.ppos2;
     const int32_t* opos = result == 1 ? pp.ppos2 : pp.ppos1;
+    // blocked list: sizes live at the SLOT that holds the node (one copy per arena, moved by the update pass), the coarse
+    // index is the block's rrel, and a shrunken subtree raises its block's re-index flag
+    const bool bpl = MCF_HAS_BPL(v);
+    const int32_t* sslot = result == 1 ? pp.slot1 : pp.slot2;
+    const int32_t* oslot = result == 1 ? pp.slot2 : pp.slot1;
+    int32_t* const zarena = bpl ? mcf_slot_sizes(v, c) : nullptr;
+    McfBlkMeta* const bmc = bpl ? (c->cur ? v.bmeta[1] : v.bmeta[0]) : nullptr;
+    int32_t* const bxa = bpl ? (c->arena ? v.bext[1] : v.bext[0]) : nullptr;
+    const int32_t bs = v.blk_shift, bmask = (1 << bs) - 1;
     for (int32_t i = k + 1 + lane; i < nstem_side; i += nlanes) {
         v.node[stem[i]].size = srec[i].size - S;
-        if (v.psz[0]) {
+        if (bpl) {
+            const int32_t sl = sslot[i];
+            zarena[sl] = srec[i].size - S;
+            MCF_ATOMIC_OR32(&bxa[sl >> bs], MCF_EXT_FLAG);
+        } else if (v.psz[0]) {
             const int32_t p = spos[i];
             v.psz[0][p] = srec[i].size - S; v.psz[1][p] = srec[i].size - S;
             if (v.reach) v.chg[i - k - 1] = p;  // its block's reach entry may now be too high: the apply pass re-indexes it
@@ -1183,7 +1553,11 @@ MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane,
     }
     for (int32_t i = lane; i < nother; i += nlanes) {
         v.node[other[i]].size = orec[i].size + S;
-        if (v.psz[0]) {
+        if (bpl) {
+            const int32_t sl = oslot[i];
+            zarena[sl] = orec[i].size + S;
+            MCF_ATOMIC_MAX32(&bmc[sl >> bs].rrel, (sl & bmask) + orec[i].size + S);  // must never be too low
+        } else if (v.psz[0]) {
             const int32_t p = opos[i];
             v.psz[0][p] = orec[i].size + S; v.psz[1][p] = orec[i].size + S;
             if (v.reach) MCF_ATOMIC_MAX32(&v.reach[p >> MCF_REACH_SHIFT], p + orec[i].size + S);  // must never be too low
@@ -1219,8 +1593,10 @@ MCF_HD void mcf_pivot_finish(const McfView& v, const McfPaths& pp, int32_t lane,
             v.seg[2 * i] = McfSeg{dst + left, pp + rp.size, right, dd};
         }
         v.node[stem[i]] = nr;
-        if (v.psz[0]) { v.psz[0][p] = nr.size; v.psz[1][p] = nr.size; }  // moved to its new position by the apply pass
+        if (bpl) zarena[sslot[i]] = nr.size;   // moved to its new slot by the update pass
+        else if (v.psz[0]) { v.psz[0][p] = nr.size; v.psz[1][p] = nr.size; }  // moved to its new position by the apply pass
     }
+    if (bpl) mcf_bpl_prepare(v, *c, lane, nlanes);
 }
 
 // Convenience for single-threaded callers (CPU emulation): the whole pivot.

@@ -382,6 +382,76 @@ inline int mcf_minor_cap(int price_blocks) {
     return r;
 }
 
+// ---- blocked preorder list (mcf_core.h): host image of the arenas, built densely from the preorder arrays of `im`
+// (slot = position), and the way back for introspection.
+struct McfBplImage {
+    int32_t shift = 0, cap = 0, dense = 0;      // log2 slots per block, blocks per arena, blocks of a dense list
+    std::vector<int32_t> tok[2], psz[2];        // [cap << shift (+ pad)] per arena
+    std::vector<int32_t> loc;                   // [n_nodes]
+    std::vector<McfBlkMeta> meta[2];            // [cap + 2]
+    std::vector<int32_t> ext[2];                // [cap]
+};
+
+// Block size by tree size (the pivot kernel reads one {base, rrel} record per block handed out: keep that pass at a few
+// thousand records) and pool size; `shift` / `pool` > 0 override (tests use tiny blocks and pools; pool < 0 = no spare
+// blocks at all, i.e. a dense rewrite on every pivot).
+inline void mcf_bpl_geometry(int32_t n_nodes, int32_t shift, int32_t pool, int32_t* shift_out, int32_t* cap_out, int32_t* dense_out) {
+    int32_t sh = shift;
+    if (sh <= 0) { sh = 6; while (sh < 10 && (n_nodes >> sh) > 4096) ++sh; }
+    if (sh < 2) sh = 2;
+    if (sh > 10) sh = 10;
+    const int32_t dense = (int32_t)(((int64_t)n_nodes + (1 << sh) - 1) >> sh);
+    int32_t extra = pool > 0 ? pool : (pool < 0 ? 0 : (dense * 3 / 2 > 256 ? dense * 3 / 2 : 256));
+    *shift_out = sh; *cap_out = dense + extra; *dense_out = dense;
+}
+
+inline void mcf_bpl_build(const McfHostImage& im, int32_t shift, int32_t pool, McfBplImage& bp) {
+    mcf_bpl_geometry(im.n_nodes, shift, pool, &bp.shift, &bp.cap, &bp.dense);
+    const int32_t B = 1 << bp.shift, N = im.n_nodes;
+    const size_t slots = ((size_t)bp.cap << bp.shift) + 4;
+    for (int a = 0; a < 2; ++a) {
+        bp.tok[a].assign(slots, 0);
+        bp.psz[a].assign(slots, 0);
+        bp.meta[a].assign((size_t)bp.cap + 2, McfBlkMeta{MCF_BLK_FREE, 0});
+        bp.ext[a].assign((size_t)bp.cap, 0);
+    }
+    bp.loc.assign((size_t)N, 0);
+    for (int32_t p = 0; p < N; ++p) {
+        bp.tok[0][p] = im.order[p];
+        bp.psz[0][p] = im.psize[p];
+        bp.loc[im.order[p]] = p;   // arena 0
+    }
+    for (int32_t b = 0; b < bp.dense; ++b) {
+        const int32_t lo = b << bp.shift, hi = lo + B < N ? lo + B : N;
+        int32_t r = 0;
+        for (int32_t p = lo; p < hi; ++p) if (p - lo + im.psize[p] > r) r = p - lo + im.psize[p];
+        bp.meta[0][b] = bp.meta[1][b] = McfBlkMeta{lo, r};
+        bp.ext[0][b] = mcf_ext_make(0, hi - lo);
+    }
+}
+
+// Logical preorder arrays from the arenas: order[p], pos[node], psize[p] (any may be null).
+// Returns false when the blocks do not tile [0, n_nodes) exactly (a corrupted list).
+inline bool mcf_bpl_flatten(int32_t n_nodes, int32_t shift, int32_t nblocks, const int32_t* tok, const int32_t* psz,
+                            const McfBlkMeta* meta, const int32_t* ext, int32_t* order, int32_t* pos, int32_t* psize) {
+    std::vector<int8_t> seen((size_t)n_nodes, 0);
+    int64_t count = 0;
+    for (int32_t b = 0; b < nblocks; ++b) {
+        if (meta[b].base == MCF_BLK_FREE) continue;
+        const int32_t beg = mcf_ext_beg(ext[b]), end = mcf_ext_end(ext[b]);
+        for (int32_t o = beg; o < end; ++o) {
+            const int32_t p = meta[b].base + o, slot = (b << shift) + o;
+            if (p < 0 || p >= n_nodes || seen[p]) return false;
+            seen[p] = 1;
+            ++count;
+            if (order) order[p] = tok[slot];
+            if (pos) pos[tok[slot]] = p;
+            if (psize) psize[p] = psz[slot];
+        }
+    }
+    return count == n_nodes;
+}
+
 struct McfHostResult {
     int32_t status = 0;        // MCF_ST_* numbering of include/mcf.h
     __int128 objective = 0;

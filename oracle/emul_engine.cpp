@@ -32,7 +32,19 @@ struct Emul {
     int price_blocks = 8;
     std::vector<McfCand> cand;  // candidate-list rule: one entry per (virtual) pricing workgroup
     McfDevex dx;                // Devex: granule table + touched-weight list
+    int bpl_shift = 0, bpl_pool = 0;   // bits 16-19 / 20-31 of the `rule` argument: blocked preorder list (0 = dense array)
+    McfBplImage bp;
 };
+
+// `rule` argument: bits 0-7 the pricing rule, 8-9 the key variant, 16-19 log2 of the block size of the blocked preorder
+// list (0: dense array), 20-31 its spare blocks (0: auto, 1: none -- every pivot rewrites the whole list --, k: k - 1).
+void decode_rule(Emul& e, int32_t rule) {
+    e.rule = rule & 0xff;
+    e.key_mode = (rule >> 8) & 3;
+    e.bpl_shift = (rule >> 16) & 15;
+    const int f = (rule >> 20) & 0xfff;
+    e.bpl_pool = f == 0 ? 0 : (f == 1 ? -1 : f - 1);
+}
 
 void bind(Emul& e) {
     McfHostImage& im = e.im;
@@ -40,8 +52,8 @@ void bind(Emul& e) {
     e.pos1 = im.pos;
     e.path1.assign(im.n_nodes, 0);
     e.path2.assign(im.n_nodes, 0);
-    e.ppos1.assign(im.n_nodes, 0);
-    e.ppos2.assign(im.n_nodes, 0);
+    e.ppos1.assign(2 * (size_t)im.n_nodes, 0);   // (blocked list: positions, then slots)
+    e.ppos2.assign(2 * (size_t)im.n_nodes, 0);
     e.rec1.assign(im.n_nodes, McfNode{0, 0, 0, 0});
     e.rec2.assign(im.n_nodes, McfNode{0, 0, 0, 0});
     e.seg.assign(2 * (size_t)im.n_nodes + 2, McfSeg{0, 0, 0, 0});
@@ -76,7 +88,7 @@ void bind(Emul& e) {
     v.prio = e.prio.empty() ? nullptr : e.prio.data();
     v.rc_partial = 0;
     v.vkey = nullptr;   // (the compressed keys ride on the resident reduced costs, which the emulation does not keep)
-    v.vk_bigm = im.big_m; v.vk_half = 1 << 28; v.vk_pad = 0;
+    v.vk_bigm = im.big_m; v.vk_half = 1 << 28;
     v.rcache = nullptr;  // the emulation always prices by gathering potentials: an independent
     v.adj_off = nullptr; // check of the engine's resident reduced costs
     v.adj = nullptr;
@@ -94,6 +106,30 @@ void bind(Emul& e) {
     v.reach = e.reach.data();
     v.chg = e.chg.data();
     for (int32_t b = 0; b < (im.n_nodes + MCF_REACH_BLOCK - 1) / MCF_REACH_BLOCK; ++b) mcf_reach_reindex_block(v, v.psz[0], b);
+    v.bmeta[0] = v.bmeta[1] = nullptr;
+    v.bext[0] = v.bext[1] = nullptr;
+    v.blk_shift = 0; v.blk_cap = 0; v.blk_pad = 0;
+    if (e.bpl_shift > 0) {
+        // blocked preorder list: the same logical preorder in physical blocks (mcf_core.h); the arenas take the place of
+        // the order / size arrays, loc[] that of the positions
+        mcf_bpl_build(im, e.bpl_shift, e.bpl_pool, e.bp);
+        for (int a = 0; a < 2; ++a) {
+            v.order[a] = e.bp.tok[a].data();
+            v.psz[a] = e.bp.psz[a].data();
+            v.bmeta[a] = e.bp.meta[a].data();
+            v.bext[a] = e.bp.ext[a].data();
+        }
+        v.posbuf[0] = e.bp.loc.data();
+        v.posbuf[1] = nullptr;
+        v.reach = nullptr;
+        e.chg.assign(std::max((size_t)im.n_nodes, 2 * (size_t)e.bp.cap + 2), 0);
+        v.chg = e.chg.data();
+        v.blk_shift = e.bp.shift;
+        v.blk_cap = e.bp.cap;
+        e.ctx.arena = 0;
+        e.ctx.alloc_next = e.bp.dense;
+        e.ctx.dense_blocks = e.bp.dense;
+    }
 }
 
 // scalar stand-in for the pricing kernel: shard r of G, Devex block = ctx.block_index of
@@ -151,6 +187,7 @@ int64_t price_minor(Emul& e, const McfCand* cands, int64_t ncand, int64_t* key, 
 void apply_all(Emul& e) {
     McfCtx& c = e.ctx;
     if (!c.apply) return;
+    if (MCF_HAS_BPL(e.view)) { mcf_bpl_update_seq(e.view, c); return; }
     // the two ranges the apply kernel covers: this pivot's and the stale one
     for (int32_t j = c.lo; j < c.hi; ++j) mcf_apply_one(e.view, c, j);
     for (int32_t j = c.prev_lo; j < c.prev_hi; ++j)
@@ -197,8 +234,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
                const int8_t* warm_in_tree /* null: cold start */, const int8_t* warm_at_upper, int32_t* warm_applied,
                const int8_t* arc_priority /* MCF_KEY_PRIORITY: caller's order; else null */) {
     Emul e;
-    e.rule = rule & 0xff;
-    e.key_mode = (rule >> 8) & 3;
+    decode_rule(e, rule);
     rule = e.rule;
     int err = 0;
     std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e.im, &err, bucketed != 0);
@@ -231,7 +267,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         mcf_pivot_seq(e.view, key, arc, rule);
         apply_all(e);
     }
-    if (c.pending_flip) { c.cur ^= 1; c.pending_flip = 0; }
+    if (c.pending_flip) { c.cur ^= 1; c.pending_flip = 0; if (c.rebuild) { c.arena ^= 1; c.rebuild = 0; } }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
     McfHostResult r;
@@ -251,8 +287,20 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     stats[8] = r.artificial_flow; stats[9] = (int64_t)(secs * 1e9);
     stats[10] = c.minor_pivots; stats[11] = c.major_sweeps;
     if (scan_stats) { scan_stats[0] = c.scans; scan_stats[1] = c.scan_rounds; }
+    std::vector<int32_t> ford, fpos, fpsz;
     const int32_t* ord = e.view.order[c.cur];
     const int32_t* pcur = e.view.posbuf[c.cur];
+    const int32_t* zcur = e.view.psz[c.cur];
+    if (MCF_HAS_BPL(e.view)) {   // the logical preorder out of the blocks
+        ford.assign((size_t)n + 1, -1); fpos.assign((size_t)n + 1, -1); fpsz.assign((size_t)n + 1, -1);
+        if (!mcf_bpl_flatten(n + 1, e.view.blk_shift, c.alloc_next, e.view.order[c.arena], e.view.psz[c.arena], e.view.bmeta[c.cur],
+                             e.view.bext[c.arena], ford.data(), fpos.data(), fpsz.data())) {
+            std::fprintf(stderr, "emul_solve: the blocked preorder list does not tile [0, n]\n");
+            return -7;
+        }
+        ord = ford.data(); pcur = fpos.data(); zcur = fpsz.data();
+        if (scan_stats) scan_stats[1] = c.rebuilds;   // (what a scan round is has no meaning here: report the dense rewrites)
+    }
     for (int32_t v = 0; v <= n; ++v) {
         if (parent) parent[v] = e.im.node[v].parent;
         if (pred_arc) {
@@ -262,7 +310,7 @@ int emul_solve(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         if (size) size[v] = e.im.node[v].size;
         if (pos) pos[v] = pcur[v];
         if (depth) depth[v] = e.im.node[v].depth;
-        if (psize) psize[v] = e.view.psz[c.cur][v];
+        if (psize) psize[v] = zcur[v];
         if (order) order[v] = ord[v];
     }
     return 0;
@@ -275,8 +323,7 @@ void* emul_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head
                   const int64_t* cap, const int64_t* supply, int32_t rule, int64_t block_size, int32_t bucketed,
                   const int8_t* arc_priority) {
     Emul* e = new Emul();
-    e->rule = rule & 0xff;
-    e->key_mode = (rule >> 8) & 3;
+    decode_rule(*e, rule);
     int err = 0;
     std::string msg = mcf_build_image(n, m, tail, head, cost, cap, supply, e->im, &err, bucketed != 0);
     if (err) { std::fprintf(stderr, "emul_create: %s\n", msg.c_str()); delete e; return nullptr; }
