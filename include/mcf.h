@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MCF_ABI_VERSION 2
+#define MCF_ABI_VERSION 3
 
 /* return codes */
 #define MCF_OK 0
@@ -124,6 +124,19 @@ typedef struct mcf_options {
                                 3 = capacity x violation (max flow, :284-335).  Not with MCF_RULE_DEVEX_BLOCK. */
     const int8_t* arc_priority; /* key_mode 2: one byte per arc, caller's order; bit 0 = preferred as a forward candidate (flow rises
                                 from the lower bound), bit 1 = preferred as a backward candidate.  Read during mcf_create only. */
+    int32_t tree_blocks;     /* layout of the spanning tree's preorder: 0 = auto (blocked preorder list from 32 768 nodes on), -1 = dense
+                                array, k in 2..10 = blocked list with blocks of 2^k slots.  The blocked list re-hangs a subtree in
+                                O(subtree + block) element moves instead of shifting every position between its old and its new
+                                place (replaces the per-pivot BFS rebuild basis.py:82-125 and _update_tree_sets simplex.py:1103-1107);
+                                same logical preorder, same pivots.  Handles of the persistent loops (pricing_mode 2 / 3, mid_loop = 1)
+                                keep the dense array. */
+    int32_t tree_pool;       /* blocked list: spare blocks per arena (0 = auto: 1.5 x the dense count; -1 = none, so that every pivot
+                                rewrites the whole list -- a test hook) */
+    int32_t rc_drop;         /* resident reduced costs are given up in mid-solve -- pricing then gathers the potentials, as with no_rcache --
+                                once the re-hung subtrees average more than this many nodes over a batch of pivots: from there on the
+                                patch of the incident arcs' reduced costs costs more per pivot than the dearer sweeps.  0 = auto
+                                (candidate list 384, Devex 2 048, Dantzig never), -1 = never, k > 0 = that threshold.  Same pivots. */
+    int32_t pad0;
 } mcf_options;
 
 typedef struct mcf_stats {
@@ -159,6 +172,9 @@ typedef struct mcf_stats {
     int64_t loop_launches;    /* ... and the number of launches (one launch runs many pivots) */
     int64_t sweep_variant;    /* which grid sweep the handle launches: bit 0 = 4-byte key codes (k_price_v), bit 1 = non-temporal
                                  loads (k_price_v<.., true>), bit 2 = incremental (clean workgroups keep their candidate) */
+    int64_t tree_blocks;      /* log2 of the block size of the blocked preorder list, 0 = dense preorder array */
+    int64_t tree_rebuilds;    /* blocked list: pivots whose update rewrote the whole list densely (the block pool had run out) */
+    int64_t rc_dropped_at;    /* pivot count at which the handle gave up its resident reduced costs (mcf_options.rc_drop), 0 = it has not */
 } mcf_stats;
 
 /* Called from mcf_solve every cb_interval pivots (simplex.py:1143-1154).

@@ -249,6 +249,11 @@ struct McfCtx {
     int32_t alloc_lo;          // first block this pivot's update may fill: two copy blocks, then the blocks of the re-hung subtree
     int32_t rebuild;           // this pivot's update writes the whole list densely into the other arena (the pool ran out)
     int32_t t_ins;             // insertion point of the re-hung subtree in OLD logical coordinates
+    int32_t t2_blk;            // the block that holds the first element of T2 (known to the pivot: the update starts on it at once)
+    int32_t ins_blk;           // the block the insertion point may cut (the new parent's block), -1: to be found by the update
+    int32_t pv_t2n;            // preview of T2 for the reduced-cost patch: 1 = T2 is the single node pv_t2node (its adjacency range
+    int32_t pv_t2node;         //   rides along, fetched while the cycle was searched), 0 = the update finds T2's nodes itself
+    int64_t pv_adj[4];         // adjacency ranges [beg, end) of the entering arc's end points: first, second
     int32_t dense_blocks;      // blocks a dense list needs: ceil(n_nodes / block)
     int64_t rebuilds;          // (diagnostic)
 };
@@ -368,6 +373,12 @@ MCF_HD int32_t mcf_node_pos(const McfView& v, const McfCtx* c, int32_t node, int
     const int32_t p = (c->cur ? v.posbuf[1] : v.posbuf[0])[node];
     *slot = p;
     return p;
+}
+// ... the slot alone (one load; the blocked list's second, dependent one -- the block's base -- is left to the caller)
+// (if / else, not a nested select of view members: that once made the compiler index the view in private memory)
+MCF_HD int32_t mcf_node_slot(const McfView& v, const McfCtx* c, int32_t node) {
+    if (MCF_HAS_BPL(v)) return v.posbuf[0][node] & MCF_LOC_SLOT;
+    return (c->cur ? v.posbuf[1] : v.posbuf[0])[node];
 }
 // the slot arrays of the current view: node id per slot, subtree size per slot
 MCF_HD const int32_t* mcf_slot_nodes(const McfView& v, const McfCtx* c) {
@@ -613,6 +624,7 @@ struct McfCycle {
     int32_t su, sw;        // ... and the slots that hold them
     McfNode ru, rw;        // their records
     int32_t p0u, p0w;      // positions and records of the entering arc's end points (first / second)
+    int32_t s0u, s0w;      // ... and their slots
     McfNode r0u, r0w;
     int32_t small;         // the scan recorded the cycle in the small (LDS) path buffers, not in v.path*/rec*/ppos*
 };
@@ -692,6 +704,13 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
     const McfArcW ae = v.arcw[e];  // one 16-byte load: capacity for the ratio test, flow for the store-only update
     c->pv_cap = ae.cap;
     c->pv_flow = ae.flow;
+    c->pv_t2n = 0;
+    if (MCF_HAS_BPL(v) && v.rcache) {
+        // the re-hung subtree contains exactly one end point of the entering arc; when it is that node alone (most pivots of
+        // a large sparse instance) the update's reduced-cost patch can start from here instead of looking the node up
+        c->pv_adj[0] = v.adj_off[first]; c->pv_adj[1] = v.adj_off[first + 1];
+        c->pv_adj[2] = v.adj_off[second]; c->pv_adj[3] = v.adj_off[second + 1];
+    }
     return true;
 }
 
@@ -711,6 +730,7 @@ MCF_HD void mcf_cycle_init(const McfView& v, McfCycle* cy) {
     cy->pw = mcf_node_pos(v, c, cy->w, &cy->sw);
     cy->r0u = cy->ru; cy->r0w = cy->rw;
     cy->p0u = cy->pu; cy->p0w = cy->pw;
+    cy->s0u = cy->su; cy->s0w = cy->sw;
     cy->small = 0;
     cy->d1 = MCF_INF; cy->d2 = MCF_INF;
     cy->k1 = -1; cy->k2 = -1;
@@ -726,52 +746,63 @@ MCF_HD int32_t mcf_climb_budget(const McfView& v, const McfCycle& cy) {
 }
 
 // Returns false on an internal error (depths out of sync).  On return cy->u == cy->w means joined.
-MCF_HD bool mcf_pivot_climb(const McfView& v, McfCycle* cy, int32_t budget) {
+// `pb`: where the path is recorded (the global scratch, or -- a climb that is known to be short -- the small LDS buffers).
+MCF_HD bool mcf_pivot_climb(const McfView& v, const McfPaths& pb, McfCycle* cy, int32_t budget) {
     McfCtx* c = v.ctx;
     // Depth-balanced climb: per round trip every side that is at least as deep as the other moves
     // up one arc (both when they are level), so the walk costs max(d1, d2) dependent loads instead of
     // d1 + d2; both parents' records and both arcs are requested before anything is looked at.
-    const McfPaths gp = mcf_view_paths(v);
-    int32_t u = cy->u, w = cy->w, pu = cy->pu, pw = cy->pw, su = cy->su, sw = cy->sw;
+    // Only the SLOT of a node is fetched on the way (one load that nothing waits for); the blocked list turns slots into
+    // positions -- a second, dependent load per node -- after the walk, all of them in flight together.
+    const bool bpl = MCF_HAS_BPL(v);
+    int32_t u = cy->u, w = cy->w, su = cy->su, sw = cy->sw;
     McfNode ru = cy->ru, rw = cy->rw;
     int64_t d1 = cy->d1, d2 = cy->d2;
     int32_t k1 = cy->k1, k2 = cy->k2, n1 = cy->n1, n2 = cy->n2;
+    const int32_t n1_in = n1, n2_in = n2;
     int32_t trips = 0;
     while (u != w && trips < budget) {
         const bool step_u = ru.depth >= rw.depth, step_w = rw.depth >= ru.depth;
         McfNode nu = ru, nw = rw;
-        int32_t npu = pu, npw = pw, nsu = su, nsw = sw;
+        int32_t nsu = su, nsw = sw;
         McfArcW au = McfArcW{0, 0}, aw = McfArcW{0, 0};
-        if (step_u) { nu = v.node[ru.parent]; npu = mcf_node_pos(v, c, ru.parent, &nsu); au = v.arcw[ru.pred >> 1]; }
-        if (step_w) { nw = v.node[rw.parent]; npw = mcf_node_pos(v, c, rw.parent, &nsw); aw = v.arcw[rw.pred >> 1]; }
+        if (step_u) { nu = v.node[ru.parent]; nsu = mcf_node_slot(v, c, ru.parent); au = v.arcw[ru.pred >> 1]; }
+        if (step_w) { nw = v.node[rw.parent]; nsw = mcf_node_slot(v, c, rw.parent); aw = v.arcw[rw.pred >> 1]; }
         if (step_u) {
             // first side is walked against the flow: an up arc loses flow, a down arc gains
             const int64_t r = (ru.pred & 1) ? au.flow : (au.cap >= MCF_INF ? MCF_INF : au.cap - au.flow);
             if (r < d1) { d1 = r; k1 = n1; }
-            v.path1[n1] = u;
-            v.rec1[n1] = ru;
-            gp.slot1[n1] = su;   // (before the position: dense array = the same word)
-            v.ppos1[n1] = pu;
+            pb.path1[n1] = u;
+            pb.rec1[n1] = ru;
+            pb.slot1[n1] = su;   // (dense array: slot and position are the same word)
+            if (pb.flow1) pb.flow1[n1] = au.flow;
             ++n1;
             u = ru.parent;
             ru = nu;
-            pu = npu;
             su = nsu;
         }
         if (step_w) {
             const int64_t r = (rw.pred & 1) ? (aw.cap >= MCF_INF ? MCF_INF : aw.cap - aw.flow) : aw.flow;
             if (r <= d2) { d2 = r; k2 = n2; }
-            v.path2[n2] = w;
-            v.rec2[n2] = rw;
-            gp.slot2[n2] = sw;
-            v.ppos2[n2] = pw;
+            pb.path2[n2] = w;
+            pb.rec2[n2] = rw;
+            pb.slot2[n2] = sw;
+            if (pb.flow2) pb.flow2[n2] = aw.flow;
             ++n2;
             w = rw.parent;
             rw = nw;
-            pw = npw;
             sw = nsw;
         }
         if (++trips > v.n_nodes) { c->status = MCF_INTERNAL_ERROR; return false; }  // depths out of sync: never spin
+    }
+    int32_t pu = su, pw = sw;
+    if (bpl) {
+        const McfBlkMeta* bm = c->cur ? v.bmeta[1] : v.bmeta[0];
+        const int32_t bs = v.blk_shift, bmask = (1 << bs) - 1;
+        for (int32_t i = n1_in; i < n1; ++i) { const int32_t sl = pb.slot1[i]; pb.ppos1[i] = bm[sl >> bs].base + (sl & bmask); }
+        for (int32_t i = n2_in; i < n2; ++i) { const int32_t sl = pb.slot2[i]; pb.ppos2[i] = bm[sl >> bs].base + (sl & bmask); }
+        pu = bm[su >> bs].base + (su & bmask);
+        pw = bm[sw >> bs].base + (sw & bmask);
     }
     cy->u = u; cy->w = w; cy->ru = ru; cy->rw = rw; cy->pu = pu; cy->pw = pw; cy->su = su; cy->sw = sw;
     cy->d1 = d1; cy->d2 = d2; cy->k1 = k1; cy->k2 = k2; cy->n1 = n1; cy->n2 = n2;
@@ -1220,6 +1251,14 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycl
         // the WHOLE list densely into the other arena instead (every position is then rewritten once).
         c->t_ins = t;
         c->nchg = 0;   // (shrunken subtrees are flagged in bext[], not listed)
+        c->t2_blk = (result == 1 ? pp.slot1 : pp.slot2)[k] >> v.blk_shift;
+        if (S == 1 && v.rcache) {   // T2 = {u_in}: first (stem on the first side) or second
+            c->pv_t2n = 1;
+            c->pv_t2node = result == 1 ? first : second;
+            if (result != 1) { c->pv_adj[0] = c->pv_adj[2]; c->pv_adj[1] = c->pv_adj[3]; }
+        }
+        // inserted directly behind v_in: the cut, if any, is in v_in's block; at the end of v_in's subtree: wherever that is
+        c->ins_blk = t == tA ? ((result == 1 ? cy.s0w : cy.s0u) >> v.blk_shift) : -1;
         const int32_t need = MCF_BLK_COPIES + ((S + (1 << v.blk_shift) - 1) >> v.blk_shift);
         c->alloc_prev = c->alloc_next;
         if (c->alloc_next + need > v.blk_cap) {
@@ -1267,6 +1306,7 @@ struct McfBlkPlan {
     int32_t nbase;              // new base of the block (MCF_BLK_FREE: nothing stays)
     int32_t r0lo, r0hi;         // logical interval (old coordinates) that stays in the block
     int32_t ilo[2], ihi[2];     // intervals cut off: [0] -> copy block alloc_lo (right of t), [1] -> alloc_lo + 1 (right of the hole)
+                                // (only ever indexed by constants)
 };
 
 MCF_HD McfBlkPlan mcf_bpl_plan(const McfCtx& c, int32_t base, int32_t L0, int32_t L1) {
@@ -1281,28 +1321,34 @@ MCF_HD McfBlkPlan mcf_bpl_plan(const McfCtx& c, int32_t base, int32_t L0, int32_
         return P;
     }
     P.touched = 1;
-    // survivors: A = [L0, min(L1, a0)) and Bv = [max(L0, a0 + S), L1); t cuts one of them strictly inside
-    int32_t lo[3], hi[3], kind[3];   // kind: what lies to the left of the interval -- 0 the cut at t, 1 the hole
+    // survivors: A = [L0, min(L1, a0)) and Bv = [max(L0, a0 + S), L1); t cuts one of them strictly inside.
+    // Three candidate runs in logical order (scalars, not arrays: the plan lives in registers); kind k: what lies to the
+    // left of run k -- 0 the cut at t, 1 the hole
     const int32_t Ahi = L1 < a0 ? L1 : a0, Blo = L0 > a0 + S ? L0 : a0 + S;
+    int32_t lo0, hi0, lo1, hi1, lo2, hi2, kind1, kind2;
     if (t <= a0) {
-        lo[0] = L0; hi[0] = t < Ahi ? t : Ahi; kind[0] = 0;
-        lo[1] = L0 > t ? L0 : t; hi[1] = Ahi; kind[1] = 0;
-        lo[2] = Blo; hi[2] = L1; kind[2] = 1;
+        lo0 = L0; hi0 = t < Ahi ? t : Ahi;
+        lo1 = L0 > t ? L0 : t; hi1 = Ahi; kind1 = 0;
+        lo2 = Blo; hi2 = L1; kind2 = 1;
     } else {
-        lo[0] = L0; hi[0] = Ahi; kind[0] = 0;
-        lo[1] = Blo; hi[1] = t < L1 ? t : L1; kind[1] = 1;
-        lo[2] = Blo > t ? Blo : t; hi[2] = L1; kind[2] = 0;
+        lo0 = L0; hi0 = Ahi;
+        lo1 = Blo; hi1 = t < L1 ? t : L1; kind1 = 1;
+        lo2 = Blo > t ? Blo : t; hi2 = L1; kind2 = 0;
     }
     bool have0 = false;
     P.r0lo = P.r0hi = 0;
     int32_t prev_hi = -1;
-    for (int q = 0; q < 3; ++q) {
-        if (hi[q] <= lo[q]) continue;
-        if (!have0) { have0 = true; P.r0lo = lo[q]; P.r0hi = hi[q]; prev_hi = hi[q]; continue; }
-        // a later run: cut off by t when it directly follows the previous run (no hole between), else by the hole
-        const int32_t kd = (lo[q] == prev_hi && kind[q] == 0) ? 0 : 1;
-        P.ilo[kd] = lo[q]; P.ihi[kd] = hi[q];
-        prev_hi = hi[q];
+    if (hi0 > lo0) { have0 = true; P.r0lo = lo0; P.r0hi = hi0; prev_hi = hi0; }
+    if (hi1 > lo1) {
+        if (!have0) { have0 = true; P.r0lo = lo1; P.r0hi = hi1; }
+        else if (lo1 == prev_hi && kind1 == 0) { P.ilo[0] = lo1; P.ihi[0] = hi1; }   // directly behind the previous run: cut off by t
+        else { P.ilo[1] = lo1; P.ihi[1] = hi1; }                                      // ... by the hole
+        prev_hi = hi1;
+    }
+    if (hi2 > lo2) {
+        if (!have0) { have0 = true; P.r0lo = lo2; P.r0hi = hi2; }
+        else if (lo2 == prev_hi && kind2 == 0) { P.ilo[0] = lo2; P.ihi[0] = hi2; }
+        else { P.ilo[1] = lo2; P.ihi[1] = hi2; }
     }
     P.nbase = have0 ? base + mcf_bpl_shift(c, P.r0lo) : MCF_BLK_FREE;
     return P;
@@ -1387,7 +1433,7 @@ MCF_HD void mcf_bpl_slot(const McfView& v, const McfCtx& c, const McfBlkPlan& P,
         return;
     } else {
         const int kd = (p >= P.ilo[0] && p < P.ihi[0]) ? 0 : 1;
-        const int32_t o = p - P.ilo[kd];
+        const int32_t o = p - (kd ? P.ilo[1] : P.ilo[0]);
         dslot = ((c.alloc_lo + kd) << bs) + o;
         out->copy_reach[kd] = o + z;
         out->moved = 1;
@@ -1465,7 +1511,7 @@ MCF_HD void mcf_pivot_walk(const McfView& v, int64_t best_key, int64_t best_arc,
     McfCycle cy;
     mcf_cycle_init(v, &cy);
     MCF_PSTAMP(14);
-    if (!mcf_pivot_climb(v, &cy, mcf_climb_budget(v, cy))) return;
+    if (!mcf_pivot_climb(v, mcf_view_paths(v), &cy, mcf_climb_budget(v, cy))) return;
     MCF_PSTAMP(15);
     if (cy.u != cy.w) {
         McfScanAcc acc;

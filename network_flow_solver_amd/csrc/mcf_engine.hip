@@ -61,12 +61,14 @@ constexpr int kMidMaxArcsPerPivot = MCF_TUNER_MAX_ARCS + 1024;  // ... and this 
 constexpr int64_t kIncrementalMinArcs = (int64_t)1 << 22;  // incremental sweeps by default from this many arcs
 constexpr int kScanMaxNodes = 1 << 27;  // (with the coarse index the scan's cost no longer grows with the tree: no practical limit)
 constexpr int kApplyThreads = 256;
+constexpr int kBplMinNodes = 200000;  // blocked preorder list from this many nodes on (auto)
 constexpr int kMaxPriceBlocks = 2048;  // 8 workgroups per CU on 256 CUs
 constexpr int kMaxApplyBlocks = 512;   // (1 024 workgroups: +5 % in the first 40 K pivots at 1 M nodes, nothing over the whole solve -- 124.5 s either way; MCF_APPLY_BLOCKS, scripts/ab_apply_blocks.py)
 #ifndef MCF_PRICE_UNROLL
 #define MCF_PRICE_UNROLL 2
 #endif
 constexpr int kUnroll = MCF_PRICE_UNROLL;  // 4-arc groups in flight per lane in k_price
+constexpr int kCtxWords = (int)(sizeof(McfCtx) / 4);   // the control block is staged in LDS word by word
 
 thread_local std::string g_create_error;
 
@@ -538,6 +540,205 @@ __global__ __launch_bounds__(kRcupdThreads) void k_update(McfView g, int apply_b
     }
 }
 
+
+// ------------------------------------------------------------------ k_update_bpl: the update over the BLOCKED preorder list
+// (mcf_core.h "blocked preorder list").  Workgroups 0 .. G-1, three phases:
+//   A  one lane per physical block handed out before this pivot (block b belongs to workgroup b % G, so that the
+//      consecutive blocks of a large subtree spread over the grid): read {base, rrel} and the live range, write the record's
+//      new copy -- for almost every block just base + shift -- or list the block as one to take apart;
+//   B  one wave per listed block, one lane per slot: T2's elements go to their new blocks (segment table, potential and
+//      depth shift on the way), cut-off runs to the copy blocks, the block's records are rewritten; the T2 nodes met are
+//      listed in LDS;
+//   C  16 lanes per listed T2 node walk its adjacency and patch the resident reduced costs / key codes of the arcs whose
+//      other end is outside T2 (mcf_bpl_in_t2: valid whether or not that node has been moved yet).
+// Workgroup G (the DIRECT one) skips A: the pivot kernel already knows two blocks that have to be taken apart -- the one T2
+// starts in and the new parent's -- so this workgroup starts on them the moment the control block has arrived, with the
+// segment table in LDS.  Almost every pivot re-hangs a handful of nodes that sit in that one block: then the whole launch
+// is   control block -> slots -> adjacency offsets -> adjacency -> reduced costs   (five dependent round trips), and the
+// membership test of the patch is a look-up in the LDS list instead of two more loads per arc.
+// With ctx.rebuild every block is taken apart (no direct workgroup) and every element lands at slot = new position in the
+// other arena.
+constexpr int kBplThreads = 1024;
+constexpr int kBplTouchedCap = 2048;   // blocks one workgroup can list (mcf_create sizes the grid so that a workgroup owns no more)
+constexpr int kBplT2Cap = 8192;        // T2 nodes one workgroup can list (more: patched on the spot by the lane that moved them)
+constexpr int kBplSegLds = 64;         // segment-table entries the direct workgroup stages in LDS
+constexpr int kBplListMember = 32;     // a T2 this small that sits in one block: membership by scanning the LDS list
+
+// `whole` != null: the listed nodes are ALL of T2 (n of them): the other end is inside iff it is in the list
+template <bool MARK>
+__device__ __forceinline__ void bpl_patch_node(const McfView& v, const McfCtx& c, int32_t u, int32_t sub, int32_t nsub,
+                                               const int32_t* whole = nullptr, int32_t n = 0) {
+    const int64_t sigma = c.sigma;
+    const int64_t beg = v.adj_off[u], end = v.adj_off[u + 1];
+    int64_t* __restrict__ rcache = v.rcache;
+    for (int64_t p = beg + sub; p < end; p += nsub) {
+        const int64_t ent = v.adj[p];
+        const int32_t other = (int32_t)(ent >> 32);
+        bool inside;
+        if (whole) { inside = false; for (int32_t q = 0; q < n; ++q) inside |= whole[q] == other; }
+        else inside = mcf_bpl_in_t2(v, c, other);
+        if (inside) continue;  // both ends inside T2: unchanged
+        const int32_t e = (int32_t)((uint32_t)ent >> 1);
+        const int64_t r = rcache[e] + ((ent & 1) ? sigma : -sigma);
+        rcache[e] = r;
+        if (v.vkey) v.vkey[e] = mcf_vkey(-(int64_t)v.state[e] * r, v.vk_bigm, v.vk_half);
+        if (MARK) mcf_mark_dirty(v, e);
+    }
+}
+
+// One wave takes block b apart (phase B).  `segv`: the view with the segment table wherever it is cheapest to search.
+template <bool MARK, bool RC>
+__device__ __forceinline__ void bpl_block(const McfView& v, const McfView& segv, const McfCtx& c, McfCtx* gctx, int32_t b, int32_t lane,
+                                          int32_t* s_t2, int32_t* s_nn) {
+    const int32_t bs = v.blk_shift;
+    const McfBlkMeta* __restrict__ bm = c.cur ? v.bmeta[1] : v.bmeta[0];
+    McfBlkMeta* __restrict__ bn = c.cur ? v.bmeta[0] : v.bmeta[1];
+    int32_t* __restrict__ xa = c.arena ? v.bext[1] : v.bext[0];
+    const int32_t* __restrict__ tok = c.arena ? v.order[1] : v.order[0];
+    const int32_t* __restrict__ psz = c.arena ? v.psz[1] : v.psz[0];
+    // the slots are requested together with the block's record (they do not depend on it): one round trip
+    constexpr int kChunks = 4;   // 64-slot chunks held in registers (blocks up to 256 slots; larger ones loop on)
+    int32_t zr[kChunks], nr[kChunks];
+#pragma unroll
+    for (int q = 0; q < kChunks; ++q) {
+        const int32_t o = q * 64 + lane;
+        const bool in = o < (1 << bs);
+        zr[q] = in ? psz[(b << bs) + o] : 0;
+        nr[q] = in ? tok[(b << bs) + o] : 0;
+    }
+    const McfBlkMeta m = bm[b];
+    const int32_t x = xa[b], beg = mcf_ext_beg(x), end = mcf_ext_end(x);
+    if (m.base == MCF_BLK_FREE || end <= beg) { if (!c.rebuild && lane == 0) bn[b] = McfBlkMeta{MCF_BLK_FREE, 0}; return; }
+    const McfBlkPlan P = mcf_bpl_plan(c, m.base, m.base + beg, m.base + end);
+    if (!c.rebuild && !P.touched && !(x & MCF_EXT_FLAG)) { if (lane == 0) bn[b] = McfBlkMeta{P.nbase, m.rrel}; return; }
+    const bool reindex_only = !c.rebuild && !P.touched;
+    int32_t keep = 0, cr0 = 0, cr1 = 0;
+    for (int32_t o0 = beg & ~63; o0 < end; o0 += 64) {
+        const int32_t o = o0 + lane, q = o0 >> 6;
+        if (o >= beg && o < end) {
+            const int32_t slot = (b << bs) + o;
+            int32_t z, nd;
+            if (q < kChunks) { z = q == 0 ? zr[0] : (q == 1 ? zr[1] : (q == 2 ? zr[2] : zr[3])); nd = q == 0 ? nr[0] : (q == 1 ? nr[1] : (q == 2 ? nr[2] : nr[3])); }
+            else { z = psz[slot]; nd = tok[slot]; }
+            if (reindex_only) { keep = keep > o + z ? keep : o + z; }
+            else {
+                const int32_t p = m.base + o;
+                McfBplOut r;
+                mcf_bpl_slot(segv, c, P, slot, p, nd, z, &r);
+                keep = keep > r.keep_reach ? keep : r.keep_reach;
+                cr0 = cr0 > r.copy_reach[0] ? cr0 : r.copy_reach[0];
+                cr1 = cr1 > r.copy_reach[1] ? cr1 : r.copy_reach[1];
+                if (RC && p >= c.t2_old && p < c.t2_old + c.t2_size) {
+                    const int32_t li = atomicAdd(s_nn, 1);
+                    if (li < kBplT2Cap) s_t2[li] = nd;
+                    else bpl_patch_node<MARK>(v, c, nd, 0, 1);   // list full: this lane patches the node's arcs itself
+                }
+            }
+        }
+    }
+    if (c.rebuild) return;   // (the old arena is left empty; its records die with the flip)
+    keep = wave_max32(keep); cr0 = wave_max32(cr0); cr1 = wave_max32(cr1);
+    if (lane == 0) {
+        bn[b] = McfBlkMeta{P.nbase, keep};
+        xa[b] = P.nbase == MCF_BLK_FREE ? 0 : mcf_ext_make(P.r0lo - m.base, P.r0hi - m.base);
+        int32_t nm = 0;
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd) {
+            const int32_t ilo = kd ? P.ilo[1] : P.ilo[0], ihi = kd ? P.ihi[1] : P.ihi[0];
+            if (ihi <= ilo) continue;
+            const int32_t cb = c.alloc_lo + kd;
+            bn[cb] = McfBlkMeta{ilo + mcf_bpl_shift(c, ilo), kd ? cr1 : cr0};
+            xa[cb] = mcf_ext_make(0, ihi - ilo);
+            nm += ihi - ilo;
+        }
+        if (nm) atomicAdd(reinterpret_cast<unsigned long long*>(&gctx->nodes_moved), (unsigned long long)nm);
+    }
+}
+
+template <bool MARK, bool RC>
+__global__ __launch_bounds__(kBplThreads) void k_update_bpl(McfView g, int G) {
+    __shared__ McfCtx cs;
+    __shared__ int32_t s_nt, s_nn;
+    __shared__ int32_t s_tb[kBplTouchedCap];
+    __shared__ int32_t s_t2[RC ? kBplT2Cap : 1];
+    __shared__ McfSeg s_seg[kBplSegLds];
+    const bool direct = (int32_t)blockIdx.x == G;
+    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&cs)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
+    if (direct && threadIdx.x >= 128 && threadIdx.x < 128 + kBplSegLds) s_seg[threadIdx.x - 128] = g.seg[threadIdx.x - 128];   // (scratch of 2 n + 2 entries: always readable)
+    if (threadIdx.x == 0) { s_nt = 0; s_nn = 0; }
+    __syncthreads();
+    const McfCtx& c = cs;
+    if (!c.apply) return;
+    McfView v = g;
+    if (!MARK) v.dirty = nullptr;
+    const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int32_t known0 = c.rebuild ? -1 : c.t2_blk, known1 = c.rebuild ? -1 : c.ins_blk;   // taken apart by the direct workgroup
+    if (direct) {
+        if (c.rebuild) return;
+        McfView segv = v;
+        if (c.nseg <= kBplSegLds) segv.seg = s_seg;
+        if (RC && c.pv_t2n == 1) {
+            // T2 is one node and the pivot kernel sent its adjacency range along: the patch needs no look-up at all
+            // (control block -> adjacency -> reduced costs); the node has no arc to itself, so every incident arc changes
+            if (wave == 0) bpl_block<MARK, false>(v, segv, c, g.ctx, known0, lane, s_t2, &s_nn);
+            else if (wave == 1 && known1 >= 0 && known1 != known0) bpl_block<MARK, false>(v, segv, c, g.ctx, known1, lane, s_t2, &s_nn);
+            else if (wave >= 2) {
+                const int64_t sigma = c.sigma;
+                for (int64_t p = c.pv_adj[0] + (threadIdx.x - 128); p < c.pv_adj[1]; p += kBplThreads - 128) {
+                    const int64_t ent = v.adj[p];
+                    const int32_t e = (int32_t)((uint32_t)ent >> 1);
+                    const int64_t r = v.rcache[e] + ((ent & 1) ? sigma : -sigma);
+                    v.rcache[e] = r;
+                    if (v.vkey) v.vkey[e] = mcf_vkey(-(int64_t)v.state[e] * r, v.vk_bigm, v.vk_half);
+                    if (MARK) mcf_mark_dirty(v, e);
+                }
+            }
+            return;
+        }
+        if (wave == 0) bpl_block<MARK, RC>(v, segv, c, g.ctx, known0, lane, s_t2, &s_nn);
+        else if (wave == 1 && known1 >= 0 && known1 != known0) bpl_block<MARK, RC>(v, segv, c, g.ctx, known1, lane, s_t2, &s_nn);
+        if (!RC) return;
+        __syncthreads();
+        const int32_t nn = s_nn < kBplT2Cap ? s_nn : kBplT2Cap;
+        const bool whole = nn == c.t2_size && nn <= kBplListMember;   // all of T2 sat in the known block
+        for (int32_t t = threadIdx.x >> 4; t < nn; t += kBplThreads / 16)
+            bpl_patch_node<MARK>(v, c, s_t2[t], threadIdx.x & 15, 16, whole ? s_t2 : nullptr, nn);
+        return;
+    }
+    const McfBlkMeta* __restrict__ bm = c.cur ? v.bmeta[1] : v.bmeta[0];
+    McfBlkMeta* __restrict__ bn = c.cur ? v.bmeta[0] : v.bmeta[1];
+    const int32_t* __restrict__ xa = c.arena ? v.bext[1] : v.bext[0];
+    const int32_t nold = c.alloc_prev;
+    // ---- A
+    for (int32_t q = threadIdx.x;; q += kBplThreads) {
+        const int32_t b = q * G + (int32_t)blockIdx.x;
+        if (b >= nold) break;
+        if (b == known0 || b == known1) continue;
+        const McfBlkMeta m = bm[b];
+        const int32_t x = xa[b], beg = mcf_ext_beg(x), end = mcf_ext_end(x);
+        if (m.base == MCF_BLK_FREE || end <= beg) { if (!c.rebuild) bn[b] = McfBlkMeta{MCF_BLK_FREE, 0}; continue; }
+        bool apart = c.rebuild != 0 || (x & MCF_EXT_FLAG) != 0;
+        if (!apart) {
+            const McfBlkPlan P = mcf_bpl_plan(c, m.base, m.base + beg, m.base + end);
+            if (P.touched) apart = true; else bn[b] = McfBlkMeta{P.nbase, m.rrel};
+        }
+        if (apart) {
+            const int32_t slot = atomicAdd(&s_nt, 1);
+            if (slot < kBplTouchedCap) s_tb[slot] = b;   // (cannot overflow: grid sized by mcf_create)
+        }
+    }
+    __syncthreads();
+    // ---- B
+    const int32_t nt = s_nt < kBplTouchedCap ? s_nt : kBplTouchedCap;
+    if (nt == 0) return;   // (uniform: the usual case for every workgroup but a few)
+    for (int32_t t = wave; t < nt; t += kBplThreads / 64) bpl_block<MARK, RC>(v, v, c, g.ctx, s_tb[t], lane, s_t2, &s_nn);
+    if (!RC) return;
+    __syncthreads();
+    // ---- C
+    const int32_t nn = s_nn < kBplT2Cap ? s_nn : kBplT2Cap;
+    for (int32_t t = threadIdx.x >> 4; t < nn; t += kBplThreads / 16) bpl_patch_node<MARK>(v, c, s_t2[t], threadIdx.x & 15, 16);
+}
+
 // ------------------------------------------------------------------ k_reduce (multi-GPU: local best -> 16 bytes)
 __global__ __launch_bounds__(kReduceThreads) void k_reduce(const McfCand* __restrict__ cand, int ncand,
                                                             McfCand* __restrict__ out) {
@@ -568,11 +769,10 @@ struct PivotShared {
     McfScanAcc acc;
     int go;  // 0 = nothing to pivot on, 1 = the climb reached the join, 2 = the scan has to finish the cycle
     McfHit hits[kHitsLds];
-    int32_t path[2][kSmallPath], ppos[2][kSmallPath];
+    int32_t path[2][kSmallPath], ppos[2][kSmallPath], pslot[2][kSmallPath];
     McfNode rec[2][kSmallPath];
     int64_t flow[2][kSmallPath];
 };
-constexpr int kCtxWords = (int)(sizeof(McfCtx) / 4);
 static_assert(sizeof(McfCtx) % 4 == 0 && kCtxWords <= kPivotThreads, "control block staging");
 
 // From the chosen entering arc to the updated flows / tree records / apply descriptor.  `v.ctx` must point at
@@ -580,6 +780,11 @@ static_assert(sizeof(McfCtx) % 4 == 0 && kCtxWords <= kPivotThreads, "control bl
 template <int NT = kPivotThreads>   // NT: threads of the calling workgroup
 __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int64_t key, int64_t arc, int32_t rule,
                                             int64_t priced) {
+    const McfPaths gp = mcf_view_paths(v);                                                    // cycle scratch in global memory
+    // ... and in LDS (dense array: a slot IS a position, one array serves both)
+    const bool bpl = MCF_HAS_BPL(v);
+    const McfPaths sp = McfPaths{S.path[0], S.path[1], S.rec[0], S.rec[1], S.ppos[0], S.ppos[1], S.flow[0], S.flow[1],
+                                 bpl ? S.pslot[0] : S.ppos[0], bpl ? S.pslot[1] : S.ppos[1]};
     if (threadIdx.x == 0) {
         McfCtx* c = v.ctx;
         if (c->pivots < c->max_pivots) c->arcs_priced += priced;  // whole-job accounting: the arcs of this pass over ALL shards
@@ -587,8 +792,15 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
         if (mcf_pivot_begin(v, key, arc, rule)) {
             MCF_PSTAMP(2);
             mcf_cycle_init(v, &S.cy);
-            // sequential part: at most climb_budget dependent round trips
-            if (mcf_pivot_climb(v, &S.cy, mcf_climb_budget(v, S.cy))) go = S.cy.u == S.cy.w ? 1 : 2;
+            // sequential part: at most climb_budget dependent round trips.  Shallow end points (the depth gate) are climbed
+            // outright: that path is short, so it is recorded in LDS, with the arcs' flows -- decide and finish then work
+            // from LDS and the flow update is store-only, as after a scan.
+            const int32_t deep = S.cy.ru.depth > S.cy.rw.depth ? S.cy.ru.depth : S.cy.rw.depth;
+            const bool gate = v.psz[0] && deep <= c->climb_depth && deep < kSmallPath;
+            bool ok;
+            if (gate) { ok = mcf_pivot_climb(v, sp, &S.cy, INT32_MAX); S.cy.small = 1; }
+            else ok = mcf_pivot_climb(v, gp, &S.cy, mcf_climb_budget(v, S.cy));
+            if (ok) go = S.cy.u == S.cy.w ? 1 : 2;
             if (go == 2) mcf_scan_init(&S.acc);
         }
         S.go = go;
@@ -596,8 +808,6 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
     __syncthreads();
     MCF_PSTAMP(3);
     const int go = S.go;
-    const McfPaths gp = mcf_view_paths(v);                                                    // cycle scratch in global memory
-    const McfPaths sp = McfPaths{S.path[0], S.path[1], S.rec[0], S.rec[1], S.ppos[0], S.ppos[1], S.flow[0], S.flow[1]};  // ... and in LDS
     if (go == 2) mcf_pivot_scan(v, sp, kSmallPath, &S.cy, &S.acc, S.hits, kHitsLds, threadIdx.x, NT);  // barriers inside
     // S.cy.small is written by lane 0 at the very end of the scan: lane 0 may use it at once, the others after the barrier.
     // Separate calls for the two scratch locations: each inlined copy works on one known address space.
@@ -619,8 +829,10 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = __builtin_amdgcn_s_memtime(); }
 #endif
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&S.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
-    McfCand first = McfCand{0, -1};
-    if ((int)threadIdx.x < ncand) first = cand[threadIdx.x];  // in flight together with the control block
+    // the first two candidates of every lane are in flight together with the control block (the grid leaves at most 2 048)
+    McfCand first = McfCand{0, -1}, second = McfCand{0, -1};
+    if ((int)threadIdx.x < ncand) first = cand[threadIdx.x];
+    if ((int)threadIdx.x + kPivotThreads < ncand) second = cand[threadIdx.x + kPivotThreads];
     __syncthreads();
     McfView v = g;
     v.ctx = &S.ctx;
@@ -641,8 +853,26 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     int64_t priced = minor ? ncand : v.m;
     if (threadIdx.x == 0 && rule == MCF_RULE_DEVEX_BLOCK && v.dx && S.ctx.num_blocks > 1)
         priced = mcf_devex_block_arcs(v.dx, (int32_t)S.ctx.block_index, S.ctx.block_granules);
+    if (minor && v.rcache && !v.rc_partial) {
+        // re-pricing from the resident reduced costs: state and reduced cost of both listed arcs of a lane are requested
+        // at once, unconditionally (a dead entry reads arc 0) -- ONE round trip for the whole list instead of a chain of
+        // candidate -> state -> reduced cost per entry (measured at 2 048 entries: 5.6 us of a 17 us launch)
+        const int64_t e0 = first.arc < 0 ? 0 : (first.arc & 0xffffffff), e1 = second.arc < 0 ? 0 : (second.arc & 0xffffffff);
+        const int32_t s0 = v.state[e0], s1 = v.state[e1];
+        const int64_t r0 = v.rcache[e0], r1 = v.rcache[e1];
+        const int64_t v0 = -(int64_t)s0 * r0, v1 = -(int64_t)s1 * r1;
+        const int64_t k0 = (first.arc >= 0 && v0 > 0) ? mcf_dantzig_key(v, e0, v0, s0) : 0;
+        const int64_t k1 = (second.arc >= 0 && v1 > 0) ? mcf_dantzig_key(v, e1, v1, s1) : 0;
+        if (mcf_cand_better(k0, first.arc, key, arc)) { key = k0; arc = first.arc; }
+        if (mcf_cand_better(k1, second.arc, key, arc)) { key = k1; arc = second.arc; }
+        for (int i = threadIdx.x + 2 * kPivotThreads; i < ncand; i += kPivotThreads) {   // (longer gathered lists)
+            const McfCand cd = cand[i];
+            const int64_t kk = mcf_minor_key(v, cd.arc);
+            if (mcf_cand_better(kk, cd.arc, key, arc)) { key = kk; arc = cd.arc; }
+        }
+    } else
     for (int i = threadIdx.x; i < ncand; i += kPivotThreads) {
-        const McfCand cd = i == (int)threadIdx.x ? first : cand[i];
+        const McfCand cd = i == (int)threadIdx.x ? first : (i == (int)threadIdx.x + kPivotThreads ? second : cand[i]);
         const int64_t kk = minor ? mcf_minor_key(v, cd.arc) : cd.key;
         if (mcf_cand_better(kk, cd.arc, key, arc)) { key = kk; arc = cd.arc; }
     }
@@ -1301,6 +1531,11 @@ struct mcf_handle {
     bool nt_sweep = false;       // the key-code sweep is larger than the Infinity Cache: non-temporal loads
     int32_t *d_pos0 = nullptr, *d_pos1 = nullptr, *d_psz0 = nullptr, *d_psz1 = nullptr;
     int32_t *d_reach = nullptr, *d_chg = nullptr;  // coarse index over the position-space sizes + its scratch
+    // blocked preorder list (large trees): d_order0/1 and d_psz0/1 are then the two slot arenas, d_pos0 is loc[]
+    bool bpl = false;
+    int bpl_shift = 0, bpl_cap = 0, bpl_dense = 0, bpl_grid = 1;
+    McfBlkMeta* d_bmeta[2] = {nullptr, nullptr};
+    int32_t* d_bext[2] = {nullptr, nullptr};
     McfDirty* d_dirty = nullptr;
     int64_t* d_swept = nullptr;  // arcs swept per pricing workgroup (summed by mcf_get_result)
     McfDevex* d_dx = nullptr;        // Devex: granule table + touched-weight list
@@ -1340,6 +1575,12 @@ struct mcf_handle {
     int64_t total_cap = 0;
     std::string err;
     bool solved_once = false;
+    // resident reduced costs -> pricing from the potentials, once the re-hung subtrees have grown so large that patching
+    // the reduced costs of their incident arcs costs more per pivot than the dearer sweeps (mcf_solve decides between batches)
+    bool rc_able = false;      // the handle was created with resident reduced costs
+    bool rc_dropped = false;   // ... and has stopped keeping them (until the next reset / warm start)
+    int64_t rc_drop_subtree = 0;   // average |T2| over a batch from which on they are dropped (0: never)
+    int64_t sw_pivots = 0, sw_subtree = 0;   // counters at the last look
     bool ctx_current = false;  // *h_ctx equals the device control block (no kernel was enqueued since it was read)
     bool external_driver = false;  // the caller enqueues the pivots itself (mcf_enqueue_*), possibly by replaying a graph it
                                    // captured: the library cannot know when the control block changes, so every read goes to the device
@@ -1439,6 +1680,15 @@ hipError_t h2d(mcf_handle* h, void* dst, const void* src, size_t bytes) {
 int upload_image(mcf_handle* h) {
     const McfHostImage& im = h->im;
     t_stage.used = 0;   // (everything staged below is synchronised before this function returns)
+    if (h->rc_dropped) {   // a fresh start keeps the reduced costs resident again
+        h->rc_dropped = false;
+        h->rcached = true;
+        h->view.rcache = h->d_rcache; h->view.vkey = h->d_vkey; h->view.dirty = h->d_dirty;
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+        h->graph_batch = 0;
+    }
+    h->sw_pivots = 0; h->sw_subtree = 0;
     HIP_TRY(h, h2d(h, h->d_tail, im.tail.data(), im.m_pad * 4));
     HIP_TRY(h, h2d(h, h->d_head, im.head.data(), im.m_pad * 4));
     HIP_TRY(h, h2d(h, h->d_cost, im.cost.data(), im.m_pad * 4));
@@ -1448,11 +1698,26 @@ int upload_image(mcf_handle* h) {
     HIP_TRY(h, h2d(h, h->d_arcw, im.arcw.data(), im.arcw.size() * sizeof(McfArcW)));
     HIP_TRY(h, h2d(h, h->d_pi, im.pi.data(), im.pi.size() * 8));
     HIP_TRY(h, h2d(h, h->d_node, im.node.data(), im.node.size() * sizeof(McfNode)));
+    std::vector<int32_t> reach;  // (outlives the asynchronous copy: synchronised at the end of this function)
+    McfBplImage bp;              // (likewise)
+    if (h->bpl) {
+        // blocked preorder list: the dense image cut into blocks (slot = position), both meta copies alike, arena 1 empty
+        mcf_bpl_build(im, h->bpl_shift, h->bpl_cap - h->bpl_dense > 0 ? h->bpl_cap - h->bpl_dense : -1, bp);
+        if (bp.cap != h->bpl_cap || bp.shift != h->bpl_shift) { h->err = "internal: blocked-list geometry"; return MCF_E_INTERNAL; }
+        HIP_TRY(h, hipMemcpyAsync(h->d_order0, bp.tok[0].data(), bp.tok[0].size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_psz0, bp.psz[0].data(), bp.psz[0].size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_psz1, 0, bp.psz[1].size() * 4, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_pos0, bp.loc.data(), bp.loc.size() * 4, hipMemcpyHostToDevice, h->stream));
+        for (int a = 0; a < 2; ++a) {
+            HIP_TRY(h, hipMemcpyAsync(h->d_bmeta[a], bp.meta[a].data(), bp.meta[a].size() * sizeof(McfBlkMeta), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_bext[a], bp.ext[a].data(), bp.ext[a].size() * 4, hipMemcpyHostToDevice, h->stream));
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));   // (pageable sources)
+    } else {
     HIP_TRY(h, h2d(h, h->d_order0, im.order.data(), im.order.size() * 4));
     HIP_TRY(h, h2d(h, h->d_order1, im.order.data(), im.order.size() * 4));
     HIP_TRY(h, h2d(h, h->d_pos0, im.pos.data(), im.pos.size() * 4));
     HIP_TRY(h, h2d(h, h->d_pos1, im.pos.data(), im.pos.size() * 4));
-    std::vector<int32_t> reach;  // (outlives the asynchronous copy: synchronised at the end of this function)
     if (h->d_psz0) {
         HIP_TRY(h, h2d(h, h->d_psz0, im.psize.data(), im.psize.size() * 4));
         HIP_TRY(h, h2d(h, h->d_psz1, im.psize.data(), im.psize.size() * 4));
@@ -1465,6 +1730,7 @@ int upload_image(mcf_handle* h) {
             }
             HIP_TRY(h, h2d(h, h->d_reach, reach.data(), reach.size() * 4));
         }
+    }
     }
     if (h->rcached)
         HIP_TRY(h, h2d(h, h->d_rcache, im.rcache.data(), im.m_pad * 8));
@@ -1490,6 +1756,7 @@ int upload_image(mcf_handle* h) {
     // shallow end points are climbed outright: one round trip per level beats the scan's fixed passes up to ~3 levels at
     // mid size (one plain round) and ~8 levels where the coarse index is used (two passes over up to 16 K words first)
     c.climb_depth = h->opt.climb_depth > 0 ? h->opt.climb_depth : (h->opt.climb_depth < 0 ? 0 : (im.n_nodes > 32768 ? 8 : 3));
+    if (h->bpl) { c.arena = 0; c.alloc_next = h->bpl_dense; c.dense_blocks = h->bpl_dense; }
     *h->h_ctx = c;
     if (h->shards > 1 && !h->d_full_tab) {
         int32_t tab[MCF_NUM_BUCKETS * 2];
@@ -1569,6 +1836,13 @@ void launch_k_pivot(mcf_handle* h, hipStream_t s, const McfCand* cand, int ncand
 }
 
 void launch_apply(mcf_handle* h, hipStream_t s) {
+    if (h->bpl) {  // blocked preorder list: block records, T2 move and reduced-cost patch in one launch
+        const dim3 grid(h->bpl_grid + 1), block(kBplThreads);   // (+1: the direct workgroup)
+        if (!h->rcached) hipLaunchKernelGGL((k_update_bpl<false, false>), grid, block, 0, s, h->view, h->bpl_grid);
+        else if (h->view.dirty) hipLaunchKernelGGL((k_update_bpl<true, true>), grid, block, 0, s, h->view, h->bpl_grid);
+        else hipLaunchKernelGGL((k_update_bpl<false, true>), grid, block, 0, s, h->view, h->bpl_grid);
+        return;
+    }
     if (h->rcached) {  // tree/potential update and reduced-cost update in one launch
         if (h->view.dirty) hipLaunchKernelGGL(k_update<true>, dim3(h->apply_blocks + h->rcupd_blocks), dim3(kRcupdThreads), 0, s, h->view, h->apply_blocks);
         else hipLaunchKernelGGL(k_update<false>, dim3(h->apply_blocks + h->rcupd_blocks), dim3(kRcupdThreads), 0, s, h->view, h->apply_blocks);
@@ -1694,6 +1968,7 @@ void free_all(mcf_handle* h) {
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
     (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_reach); (void)hipFree(h->d_chg); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_dx); (void)hipFree(h->d_full_tab);
     (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj); (void)hipFree(h->d_vkey);
+    for (int a = 0; a < 2; ++a) { (void)hipFree(h->d_bmeta[a]); (void)hipFree(h->d_bext[a]); }
     if (h->h_ctx) pinned_give(reinterpret_cast<char*>(h->h_ctx));   // (h_one lives in the same slot)
     if (h->stream && h->stream_owned) (void)hipStreamDestroy(h->stream);
 }
@@ -1759,6 +2034,24 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     }
     const McfHostImage& im = h->im;
     {
+        // Tree layout: the blocked preorder list (mcf_core.h) from kBplMinNodes nodes on -- below that the dense array's block
+        // permutation moves few enough positions, and the persistent loops keep the dense array anyway.
+        // tree_blocks: 0 = auto, -1 = dense array, k >= 2 = blocks of 2^k slots;  tree_pool: spare blocks (0 = auto, -1 = none).
+        const bool forced = opt.tree_blocks > 0, never = opt.tree_blocks < 0;
+        h->bpl = !never && opt.mid_loop <= 0 && opt.overlap_update <= 0 && (forced || im.n_nodes >= kBplMinNodes);
+        if (h->bpl) {
+            int32_t sh = 0, cap = 0, dense = 0;
+            mcf_bpl_geometry(im.n_nodes, forced ? opt.tree_blocks : 0, opt.tree_pool, &sh, &cap, &dense);
+            h->bpl_shift = sh; h->bpl_cap = cap; h->bpl_dense = dense;
+            int g = (cap + 7) / 8;
+            if (g > 256) g = 256;
+            if (g < 1) g = 1;
+            while ((cap + g - 1) / g > kBplTouchedCap) g *= 2;
+            if (const char* ge = std::getenv("MCF_BPL_GRID")) { const int vv = std::atoi(ge); if (vv >= g && vv <= 4096) g = vv; }   // A/B switch
+            h->bpl_grid = g;
+        }
+    }
+    {
         // 8 * k workgroups, one group of k per XCD head bucket (formula shared with the CPU emulation)
         h->price_blocks = mcf_price_blocks(m, h->shards, opt.price_blocks);
         const int64_t ab = ((int64_t)im.n_nodes + kApplyThreads - 1) / kApplyThreads;
@@ -1786,14 +2079,15 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     if ((e = dalloc(&h->d_arcw, im.arcw.size())) != hipSuccess) return fail("hipMalloc arcw", e);
     if ((e = dalloc(&h->d_pi, N)) != hipSuccess) return fail("hipMalloc pi", e);
     if ((e = dalloc(&h->d_node, N)) != hipSuccess) return fail("hipMalloc node", e);
-    if ((e = dalloc(&h->d_order0, N)) != hipSuccess) return fail("hipMalloc order", e);
-    if ((e = dalloc(&h->d_order1, N)) != hipSuccess) return fail("hipMalloc order", e);
+    const size_t bpl_slots = h->bpl ? ((size_t)h->bpl_cap << h->bpl_shift) + 4 : 0;   // slots per arena (+4: groups of four)
+    if ((e = dalloc(&h->d_order0, h->bpl ? bpl_slots : N)) != hipSuccess) return fail("hipMalloc order", e);
+    if ((e = dalloc(&h->d_order1, h->bpl ? bpl_slots : N)) != hipSuccess) return fail("hipMalloc order", e);
     if ((e = dalloc(&h->d_pos0, N)) != hipSuccess) return fail("hipMalloc pos", e);
-    if ((e = dalloc(&h->d_pos1, N)) != hipSuccess) return fail("hipMalloc pos", e);
+    if ((e = dalloc(&h->d_pos1, h->bpl ? 1 : N)) != hipSuccess) return fail("hipMalloc pos", e);
     if ((e = dalloc(&h->d_path1, N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_path2, N)) != hipSuccess) return fail("hipMalloc path", e);
-    if ((e = dalloc(&h->d_ppos1, N)) != hipSuccess) return fail("hipMalloc path", e);
-    if ((e = dalloc(&h->d_ppos2, N)) != hipSuccess) return fail("hipMalloc path", e);
+    if ((e = dalloc(&h->d_ppos1, h->bpl ? 2 * N : N)) != hipSuccess) return fail("hipMalloc path", e);   // (blocked list: positions, then slots)
+    if ((e = dalloc(&h->d_ppos2, h->bpl ? 2 * N : N)) != hipSuccess) return fail("hipMalloc path", e);
     if ((e = dalloc(&h->d_rec1, N)) != hipSuccess) return fail("hipMalloc rec", e);
     if ((e = dalloc(&h->d_rec2, N)) != hipSuccess) return fail("hipMalloc rec", e);
     if ((e = dalloc(&h->d_seg, 2 * N + 2)) != hipSuccess) return fail("hipMalloc seg", e);
@@ -1849,7 +2143,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         L.seg = take((2 * Nn + 2) * sizeof(McfSeg)); L.ctx = take(sizeof(McfCtx));
         L.total = off;
         const uint64_t need = mp * 21 + (uint64_t)im.arcw.size() * 16 + Nn * 112 + 4096;
-        h->small = !opt.no_fused && !opt.profile && h->shards == 1 && need < 150 * 1024 && L.total <= kSmallMaxLds;
+        h->small = !h->bpl && !opt.no_fused && !opt.profile && h->shards == 1 && need < 150 * 1024 && L.total <= kSmallMaxLds;
         if (h->small) {
             // (the limit is a property of the kernel, not of the handle: it only ever grows, so that handles of different
             //  sizes can be alive together -- and share one batched launch)
@@ -1869,7 +2163,24 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     }
     // position-space subtree sizes for the cycle scan: every handle but the LDS-resident ones
     const bool scan_ok = opt.cycle_scan >= 0 && im.n_nodes <= kScanMaxNodes && !h->small;  // -1: never scan
-    if (scan_ok) {
+    v.bmeta[0] = v.bmeta[1] = nullptr; v.bext[0] = v.bext[1] = nullptr; v.blk_shift = 0; v.blk_cap = 0; v.blk_pad = 0;
+    if (h->bpl) {
+        // the two slot arenas (sizes; node ids are d_order0/1), the block records (two copies) and extents (one per arena),
+        // and the scratch the scan spills flagged blocks to
+        if ((e = dalloc(&h->d_psz0, bpl_slots)) != hipSuccess) return fail("hipMalloc psz", e);
+        if ((e = dalloc(&h->d_psz1, bpl_slots)) != hipSuccess) return fail("hipMalloc psz", e);
+        if ((e = hipMemset(h->d_psz0, 0, bpl_slots * 4)) != hipSuccess || (e = hipMemset(h->d_psz1, 0, bpl_slots * 4)) != hipSuccess) return fail("hipMemset psz", e);
+        for (int a = 0; a < 2; ++a) {
+            if ((e = dalloc(&h->d_bmeta[a], (size_t)h->bpl_cap + 2)) != hipSuccess) return fail("hipMalloc block records", e);
+            if ((e = dalloc(&h->d_bext[a], (size_t)h->bpl_cap)) != hipSuccess) return fail("hipMalloc block extents", e);
+            v.bmeta[a] = h->d_bmeta[a]; v.bext[a] = h->d_bext[a];
+        }
+        const size_t nchg = std::max(N, 2 * (size_t)h->bpl_cap + 2);
+        if ((e = dalloc(&h->d_chg, nchg)) != hipSuccess) return fail("hipMalloc chg", e);
+        v.psz[0] = h->d_psz0; v.psz[1] = h->d_psz1;
+        v.chg = h->d_chg;
+        v.blk_shift = h->bpl_shift; v.blk_cap = h->bpl_cap;
+    } else if (scan_ok) {
         const size_t NP = (N + MCF_REACH_BLOCK - 1) / MCF_REACH_BLOCK * MCF_REACH_BLOCK + 4;  // whole coarse blocks (+4: groups of four)
         if ((e = dalloc(&h->d_psz0, NP)) != hipSuccess) return fail("hipMalloc psz", e);
         if ((e = dalloc(&h->d_psz1, NP)) != hipSuccess) return fail("hipMalloc psz", e);
@@ -1884,7 +2195,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     // preorder positions finishes the cycle.  Auto = none: measured on MI355X (profiles/r01_f_*), scanning
     // at once beats every hybrid from 256 to 65 536 nodes -- a dependent global round trip per tree level
     // costs more than the whole scan's ~4 -- by 1.1x (netgen_8_08a) to 4.5x (goto_8_16a, cycles of ~450 arcs).
-    if (!scan_ok) h->climb_budget = INT32_MAX;
+    if (!scan_ok && !(h->bpl && opt.cycle_scan >= 0)) h->climb_budget = INT32_MAX;
     else if (opt.cycle_scan > 0) h->climb_budget = opt.cycle_scan - 1;
     else h->climb_budget = 0;
     // resident reduced costs for everything that does not take the fused LDS path
@@ -1923,13 +2234,13 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         }
         // (the candidate list never gains from the loop -- its full sweeps run on the grid either way -- and stays on the graph)
         const bool fits = im.n_nodes <= kMidMaxNodes && per_pivot_arcs <= kMidMaxArcsPerPivot && opt.rule != MCF_RULE_CANDIDATE_LIST;
-        h->mid = h->rcached && scan_ok && h->shards == 1 && !opt.profile && opt.mid_loop >= 0 && (fits || opt.mid_loop > 0);
+        h->mid = !h->bpl && h->rcached && scan_ok && h->shards == 1 && !opt.profile && opt.mid_loop >= 0 && (fits || opt.mid_loop > 0);
     }
     // overlapped graphs (build_graph), on request only: the idea -- on large trees the permutation outlasts the reduced-cost
     // patch, so the next pricing could hide beside it -- loses to the cost of the two cross-queue edges per pivot
     // (netgen_8_14a 55 K -> 33 K pivots/s, 1 M / 16 M 26 K -> 22 K; profiles/r02_ab_overlapped_graph.txt)
     {
-        const bool able = h->rcached && !h->small && !h->mid && h->shards == 1 && !opt.profile && opt.rule != MCF_RULE_CANDIDATE_LIST;
+        const bool able = !h->bpl && h->rcached && !h->small && !h->mid && h->shards == 1 && !opt.profile && opt.rule != MCF_RULE_CANDIDATE_LIST;
         h->overlap = able && opt.overlap_update > 0;
         if (h->overlap && (e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     }
@@ -1967,6 +2278,19 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         }
         if ((e = hipMemcpy(h->d_dirty, &head, offsetof(McfDirty, flag), hipMemcpyHostToDevice)) != hipSuccess) return fail("copy dirty", e);
         v.dirty = h->d_dirty;
+    }
+    h->rc_able = h->rcached;
+    {
+        // auto: candidate lists (one sweep per ~33 pivots) from an average |T2| of 384 nodes, Devex (one block per pivot) from
+        // 2 048; never for the Dantzig rule, whose every pivot sweeps all arcs, for shards (their driver owns the launches) or
+        // the persistent loops.  rc_drop: -1 = never, k > 0 = that threshold.
+        int64_t thr = 0;
+        if (h->rcached && !h->mid && !h->small && h->shards == 1 && opt.key_mode == 0 && !opt.forward_first) {
+            if (opt.rc_drop > 0) thr = opt.rc_drop;
+            else if (opt.rc_drop == 0) thr = opt.rule == MCF_RULE_CANDIDATE_LIST ? 384 : (opt.rule == MCF_RULE_DEVEX_BLOCK ? 2048 : 0);
+        }
+        if (const char* env = std::getenv("MCF_RC_DROP")) { const long vv = std::atol(env); thr = vv > 0 ? vv : 0; }   // A/B switch
+        h->rc_drop_subtree = h->rcached && h->shards == 1 ? thr : 0;
     }
     const int rc = upload_image(h);   // (ends with a synchronisation of h->stream)
     if (rc != MCF_OK) { g_create_error = h->err; free_all(h); delete h; return rc; }
@@ -2096,6 +2420,30 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
             }
             h->stats.batches += 1;
             if (h->h_ctx->status != MCF_RUNNING) break;
+            // Drop the resident reduced costs?  Their patch walks the adjacency of every node of the re-hung subtree: a few
+            // arcs early in a solve, hundreds of thousands of random read-modify-writes per pivot once subtrees of thousands
+            // of nodes move (1 M / 16 M, last third of the solve: 20+ us of a pivot).  Pricing from the potentials costs a
+            // dearer sweep instead (gathers), which a candidate-list handle pays once per minor_cap + 1 pivots and a Devex
+            // handle on one block.  Same keys, same candidates, same pivots; one way (until the next reset).
+            if (h->rcached && h->rc_drop_subtree > 0 && !h->opt.profile) {
+                const int64_t dp = h->h_ctx->pivots - h->sw_pivots, ds = h->h_ctx->subtree_nodes - h->sw_subtree;
+                if (dp >= 4096) {
+                    h->sw_pivots = h->h_ctx->pivots; h->sw_subtree = h->h_ctx->subtree_nodes;
+                    if (ds >= dp * h->rc_drop_subtree) {
+                        h->rc_dropped = true;
+                        h->rcached = false;
+                        h->view.rcache = nullptr; h->view.vkey = nullptr; h->view.dirty = nullptr;
+                        h->stats.rc_dropped_at = h->h_ctx->pivots;
+                        if (graph) {
+                            (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr;
+                            (void)hipGraphDestroy(h->graph); h->graph = nullptr;
+                            h->graph_batch = 0;
+                            rc = build_graph(h, batch);
+                            if (rc) return rc;
+                        }
+                    }
+                }
+            }
         }
         const int32_t st = h->h_ctx->status;
         if (st == MCF_PIVOT_LIMIT && h->h_ctx->pivots < final_cap) {
@@ -2281,6 +2629,7 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
         h->stats.artificial_flow = r.artificial_flow;
         h->stats.pricing_mode = h->small ? 2 : (h->mid ? 3 : (h->rcached ? 1 : 0));
         h->stats.sweep_variant = ((h->view.vkey && h->opt.rule != MCF_RULE_DEVEX_BLOCK) ? 1 : 0) | (h->view.vkey && h->nt_sweep ? 2 : 0) | (h->view.dirty ? 4 : 0);
+        h->stats.tree_blocks = h->bpl ? h->bpl_shift : 0; h->stats.tree_rebuilds = c.rebuilds;
         h->stats.cycle_scans = c.scans; h->stats.scan_rounds = c.scan_rounds; {
             h->stats.arcs_swept = c.arcs_priced;  // full sweeps read what they cover ...
             if (h->view.dirty) {                   // ... incremental ones count per pricing workgroup
@@ -2506,6 +2855,29 @@ int mcf_get_tree(mcf_handle* h, int32_t* parent, int32_t* pred_arc, int32_t* siz
         if (depth) depth[v] = nodes[v].depth;
     }
     const int cur = h->h_ctx->cur ^ (h->h_ctx->pending_flip ? 1 : 0);
+    if (h->bpl) {
+        // blocked preorder list: flatten the blocks handed out so far into the logical arrays the dense layout would hold
+        const int arena = h->h_ctx->arena ^ ((h->h_ctx->pending_flip && h->h_ctx->rebuild) ? 1 : 0);
+        const int32_t nb = h->h_ctx->alloc_next;
+        const size_t slots = (size_t)nb << h->bpl_shift;
+        std::vector<int32_t> tok(slots), psz(slots), ext((size_t)nb);
+        std::vector<McfBlkMeta> meta((size_t)nb);
+        HIP_TRY(h, hipMemcpy(tok.data(), arena ? h->d_order1 : h->d_order0, slots * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(psz.data(), arena ? h->d_psz1 : h->d_psz0, slots * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(meta.data(), h->d_bmeta[cur], (size_t)nb * sizeof(McfBlkMeta), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(ext.data(), h->d_bext[arena], (size_t)nb * 4, hipMemcpyDeviceToHost));
+        std::vector<int32_t> ford((size_t)im.n_nodes, -1), fpos((size_t)im.n_nodes, -1), fpsz((size_t)im.n_nodes, -1);
+        if (!mcf_bpl_flatten(im.n_nodes, h->bpl_shift, nb, tok.data(), psz.data(), meta.data(), ext.data(), ford.data(), fpos.data(), fpsz.data())) {
+            h->err = "internal error: the blocked preorder list does not tile the positions";
+            return MCF_E_INTERNAL;
+        }
+        for (int32_t v = 0; v < im.n_nodes; ++v) {
+            if (order) order[v] = ford[v];
+            if (pos) pos[v] = fpos[v];
+            if (psize) psize[v] = fpsz[v];
+        }
+        order = nullptr; pos = nullptr; psize = nullptr;
+    }
     if (order) HIP_TRY(h, hipMemcpy(order, cur ? h->d_order1 : h->d_order0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
     if (pos) HIP_TRY(h, hipMemcpy(pos, cur ? h->d_pos1 : h->d_pos0, (size_t)im.n_nodes * 4, hipMemcpyDeviceToHost));
     if (psize) {

@@ -19,7 +19,7 @@ from .exceptions import NetworkSolverError
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MCF_HIP_LIB", _PKG / "libmcf_hip.so"))  # override: A/B builds of the same ABI
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 RULE_DANTZIG = 0
 RULE_DEVEX_BLOCK = 1
 RULE_CANDIDATE_LIST = 2
@@ -57,6 +57,7 @@ class McfOptions(ctypes.Structure):
         ("devex_tuner", ctypes.c_int32), ("devex_stay", ctypes.c_int32), ("forward_first", ctypes.c_int32),
         ("compressed_keys", ctypes.c_int32), ("vkey_half_log2", ctypes.c_int32), ("climb_depth", ctypes.c_int32),
         ("overlap_update", ctypes.c_int32), ("key_mode", ctypes.c_int32), ("arc_priority", ctypes.POINTER(ctypes.c_int8)),
+        ("tree_blocks", ctypes.c_int32), ("tree_pool", ctypes.c_int32), ("rc_drop", ctypes.c_int32), ("pad0", ctypes.c_int32),
     ]
 
 
@@ -71,6 +72,7 @@ class McfStats(ctypes.Structure):
         ("artificial_flow", ctypes.c_int64), ("pricing_mode", ctypes.c_int64),
         ("cycle_scans", ctypes.c_int64), ("scan_rounds", ctypes.c_int64), ("arcs_swept", ctypes.c_int64),
         ("loop_ms", ctypes.c_double), ("loop_launches", ctypes.c_int64), ("sweep_variant", ctypes.c_int64),
+        ("tree_blocks", ctypes.c_int64), ("tree_rebuilds", ctypes.c_int64), ("rc_dropped_at", ctypes.c_int64),
     ]
 
     def as_dict(self) -> dict:
@@ -162,7 +164,8 @@ class McfEngine:
                  shard: tuple[int, int] | None = None, price_blocks: int = 0, fused: bool = True,
                  resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0, full_sweeps: int = 0,
                  devex_tuner: int = 0, devex_stay: bool = False, forward_first: bool = False, compressed_keys: int = 0,
-                 vkey_half_log2: int = 0, climb_depth: int = 0, overlap_update: int = 0, key_mode: int = 0, arc_priority=None):
+                 vkey_half_log2: int = 0, climb_depth: int = 0, overlap_update: int = 0, key_mode: int = 0, arc_priority=None,
+                 tree_blocks: int = 0, tree_pool: int = 0, rc_drop: int = 0):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -211,6 +214,11 @@ class McfEngine:
             opt.arc_priority = _p(self._arc_priority, ctypes.c_int8)
         opt.overlap_update = int(overlap_update)     # 1 = pricing of pivot t+1 beside the permutation of pivot t (A/B switch: measured slower)
         opt.climb_depth = int(climb_depth)           # 0 auto, -1 never, k: end points of depth <= k are climbed outright
+        # layout of the tree's preorder: 0 auto (blocked list from 32 768 nodes on), -1 dense array, k = blocks of 2^k slots;
+        # MCF_TREE_BLOCKS / MCF_TREE_POOL override the default (A/B runs of whole scripts)
+        opt.tree_blocks = int(tree_blocks) if tree_blocks else int(os.environ.get("MCF_TREE_BLOCKS", "0"))
+        opt.tree_pool = int(tree_pool) if tree_pool else int(os.environ.get("MCF_TREE_POOL", "0"))
+        opt.rc_drop = int(rc_drop)   # resident reduced costs given up from this average re-hung subtree size on (0 auto, -1 never)
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule

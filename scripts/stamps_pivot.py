@@ -10,6 +10,8 @@ MID = os.environ.get("MID", "0") == "1"
 names = ["stage ctx+cand" if not MID else "loop top", "minor key + argmax", "accounting+begin", "cycle_init + barrier", "scan: setup", "scan: rounds", "scan: hit pass",
          "scan: reduce+merge", "decide", "barrier+finish", "publish ctx" if not MID else "update pass (apply+rcupd)"]
 CASES = (("netgen_8_10a", 1, 10**9), ("netgen_8_12a", 1, 10**9), ("netgen_8_14a", 1, 10**9), ("netgen_8_14a", 2, 10**9)) if MID else (("netgen_8_10a", 0, 10**9), ("netgen_8_14a", 0, 10**9), ("netgen_8_14a", 2, 10**9), ("gridgen_8_14a", 1, 10**9), ("goto_8_16a", 0, 60000))
+if len(sys.argv) > 1:   # name:rule:cap ...
+    CASES = tuple((a.split(":")[0], int(a.split(":")[1]), int(a.split(":")[2])) for a in sys.argv[1:])
 for name, rule, cap in CASES:
     inst = generators.named_instance(name)
     eng = engine.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, mid_loop=1 if MID else -1)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(engine.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert engine.load_library().mcf_abi_version() == engine.ABI_VERSION == 2
+    assert engine.load_library().mcf_abi_version() == engine.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_the_header():
