@@ -148,6 +148,18 @@ struct alignas(16) McfCand {
     int64_t arc;   // packed ids, -1 when none
 };
 
+// Candidate-list rule: what a minor iteration needs to know about a listed arc, kept current by the update pass of every
+// pivot (rc changes by +-sigma iff exactly one end point is in the re-hung subtree; the state changes only for the entering
+// and the leaving arc), so that re-pricing the list is ONE coalesced read of these records instead of two dependent
+// random loads per listed arc -- and the winner's end points are known without looking the arc up.
+struct alignas(16) McfCandX {
+    int64_t rc;      // exact reduced cost under the current potentials
+    int64_t arc;     // packed ids as in McfCand, -1: none
+    int32_t tail, head;
+    int32_t state;   // +1 / -1 / 0 (basic)
+    int32_t pad;
+};
+
 #define MCF_NUM_BUCKETS 8  // one head-node bucket per XCD (8 XCDs, private 4 MiB L2 each)
 
 // ---- Devex block search (simplex_pricing.py:310-357) with the reference's block-size tuner
@@ -340,7 +352,8 @@ struct McfView {
     struct McfBlkMeta* bmeta[2];
     int32_t* bext[2];
     int32_t blk_cap;        // physical blocks per arena
-    int32_t blk_pad;
+    int32_t ncandx;         // entries of candx[] (= pricing workgroups)
+    McfCandX* candx;        // candidate-list rule, single GPU: the live list's records (nullptr: minor iterations look the arcs up)
     // ---- incremental pricing (nullptr = every sweep prices every block).  A pricing workgroup's best candidate
     // only changes when an arc of its block changes reduced cost or state; the passes that change arcs raise the
     // block's flag, and a full Dantzig sweep (also the candidate-list rule's) skips the blocks whose flag is down.
@@ -648,7 +661,9 @@ struct McfScanAcc {
 
 // Step 1 (one lane): bookkeeping + the entering arc.  Returns false when there is nothing to pivot on
 // in this slot (limit reached, no candidate, ...); the control block then already says why.
-MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
+// `wx`: the winner's candidate record when the caller has it (candidate cache): state, end points and reduced cost then
+// need no look-up, and the arc's capacity / flow load does not depend on anything else the cycle search fetches.
+MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule, const McfCandX* wx = nullptr) {
     McfCtx* c = v.ctx;
     c->apply = 0;
     c->stage = 0;
@@ -694,11 +709,20 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
 
     if (rule == MCF_RULE_DEVEX_BLOCK && c->block_index >= c->num_blocks) c->block_index = 0;  // (a tuner step may have shrunk num_blocks)
     const int32_t e = (int32_t)(best_arc & 0xffffffff);  // engine index (low word of the packed id)
-    const int32_t s = v.state[e];  // +1: flow rises from 0; -1: flow falls from cap
-    const int32_t first = s > 0 ? v.tail[e] : v.head[e];
-    const int32_t second = s > 0 ? v.head[e] : v.tail[e];
-    // exact reduced cost of the entering arc (the Devex key is a merit, not a violation)
-    const int64_t rc = (v.rcache && !v.rc_partial) ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
+    int32_t s, first, second;
+    int64_t rc;
+    if (wx) {
+        s = wx->state;
+        first = s > 0 ? wx->tail : wx->head;
+        second = s > 0 ? wx->head : wx->tail;
+        rc = wx->rc;
+    } else {
+        s = v.state[e];  // +1: flow rises from 0; -1: flow falls from cap
+        first = s > 0 ? v.tail[e] : v.head[e];
+        second = s > 0 ? v.head[e] : v.tail[e];
+        // exact reduced cost of the entering arc (the Devex key is a merit, not a violation)
+        rc = (v.rcache && !v.rc_partial) ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
+    }
 
     c->pv_e = e; c->pv_s = s; c->pv_first = first; c->pv_second = second; c->pv_rc = rc;
     const McfArcW ae = v.arcw[e];  // one 16-byte load: capacity for the ratio test, flow for the store-only update
@@ -1012,21 +1036,36 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
             const int32_t ngroups = nlanes >= per ? nlanes / per : 1;
             const int32_t g = nlanes >= per ? lane / per : 0, sub0 = nlanes >= per ? lane % per : 0;
             const int32_t nsub = nlanes >= per ? 1 : per;              // a team of one lane walks the block itself
-            for (int32_t t = g; t < nf; t += ngroups) {
-                int32_t b, lbase;
-                if (t < MCF_SCAN_BLK_CAP) { b = acc->blk[t]; lbase = acc->blkbase[t]; }
-                else { b = blk_spill[2 * (t - MCF_SCAN_BLK_CAP)]; lbase = blk_spill[2 * (t - MCF_SCAN_BLK_CAP) + 1]; }
+            // MCF_SCAN_GROUPS blocks per lane group and trip: all their loads are in flight before the first is looked at
+            // (a long cycle flags hundreds of blocks; one block per trip made the pass a chain of dependent round trips)
+            for (int32_t t0 = g; t0 < nf; t0 += ngroups * MCF_SCAN_GROUPS) {
                 for (int32_t q = 0; q < nsub; ++q) {
-                    const int32_t s0 = (b << bshift) + (sub0 + q) * 4;   // slots
-                    const int32_t i0 = lbase + (sub0 + q) * 4;           // their logical positions
-                    int32_t sz[4];
+                    int32_t szk[MCF_SCAN_GROUPS][4], s0k[MCF_SCAN_GROUPS], i0k[MCF_SCAN_GROUPS];
 #if defined(__HIP_DEVICE_COMPILE__)
-                    const int4 w4 = *reinterpret_cast<const int4*>(psz + s0);
-                    sz[0] = w4.x; sz[1] = w4.y; sz[2] = w4.z; sz[3] = w4.w;
-#else
-                    for (int e = 0; e < 4; ++e) sz[e] = psz[s0 + e];
+#pragma unroll
 #endif
-                    mcf_scan_group(i0, s0, sz, pu, pw, pmin, &acc->jpos[0], acc, hits, hits_cap, spill);
+                    for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
+                        const int32_t t = t0 + k * ngroups;
+                        s0k[k] = -1; i0k[k] = 0;
+                        szk[k][0] = szk[k][1] = szk[k][2] = szk[k][3] = 0;
+                        if (t >= nf) continue;
+                        int32_t b, lbase;
+                        if (t < MCF_SCAN_BLK_CAP) { b = acc->blk[t]; lbase = acc->blkbase[t]; }
+                        else { b = blk_spill[2 * (t - MCF_SCAN_BLK_CAP)]; lbase = blk_spill[2 * (t - MCF_SCAN_BLK_CAP) + 1]; }
+                        s0k[k] = (b << bshift) + (sub0 + q) * 4;   // slots
+                        i0k[k] = lbase + (sub0 + q) * 4;           // their logical positions
+#if defined(__HIP_DEVICE_COMPILE__)
+                        const int4 w4 = *reinterpret_cast<const int4*>(psz + s0k[k]);
+                        szk[k][0] = w4.x; szk[k][1] = w4.y; szk[k][2] = w4.z; szk[k][3] = w4.w;
+#else
+                        for (int e = 0; e < 4; ++e) szk[k][e] = psz[s0k[k] + e];
+#endif
+                    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                    for (int k = 0; k < MCF_SCAN_GROUPS; ++k)
+                        if (s0k[k] >= 0) mcf_scan_group(i0k[k], s0k[k], szk[k], pu, pw, pmin, &acc->jpos[0], acc, hits, hits_cap, spill);
                 }
             }
             MCF_TEAM_BARRIER();
@@ -1252,7 +1291,7 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycl
         c->t_ins = t;
         c->nchg = 0;   // (shrunken subtrees are flagged in bext[], not listed)
         c->t2_blk = (result == 1 ? pp.slot1 : pp.slot2)[k] >> v.blk_shift;
-        if (S == 1 && v.rcache) {   // T2 = {u_in}: first (stem on the first side) or second
+        if (S == 1) {   // T2 = {u_in}: first (stem on the first side) or second (the adjacency range only rides along with resident reduced costs)
             c->pv_t2n = 1;
             c->pv_t2node = result == 1 ? first : second;
             if (result != 1) { c->pv_adj[0] = c->pv_adj[2]; c->pv_adj[1] = c->pv_adj[3]; }

@@ -113,6 +113,20 @@ __device__ __forceinline__ void block_argmax(int64_t& key, int64_t& arc) {
     }
 }
 
+// Candidate cache (McfView::candx): the record of this pricing workgroup's candidate -- end points, state and exact
+// reduced cost as of this sweep; the update pass of every following pivot keeps it current.  Thread 0, after the arg-max.
+__device__ __forceinline__ void write_candx(const McfView& v, int64_t arc) {
+    if (!v.candx) return;
+    McfCandX x;
+    x.arc = arc; x.rc = 0; x.tail = 0; x.head = 0; x.state = 0; x.pad = 0;
+    if (arc >= 0) {
+        const int64_t e = arc & 0xffffffff;
+        x.tail = v.tail[e]; x.head = v.head[e]; x.state = v.state[e];
+        x.rc = (v.rcache && !v.rc_partial) ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[x.tail] - v.pi[x.head];
+    }
+    v.candx[blockIdx.x] = x;
+}
+
 // ------------------------------------------------------------------ k_price
 // XCD-aware sweep.  Workgroups are dealt to XCDs round-robin (blockIdx % 8 share an XCD --
 // a performance observation, not a correctness assumption), so workgroup b sweeps head-bucket
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price(McfView v, int64_t shar
         }
     }
     block_argmax<kPriceThreads>(key, arc);
-    if (threadIdx.x == 0) cand[blockIdx.x] = McfCand{key, arc};
+    if (threadIdx.x == 0) { cand[blockIdx.x] = McfCand{key, arc}; write_candx(v, arc); }
 }
 
 // ------------------------------------------------------------------ k_price_rc: sweep over RESIDENT reduced costs
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_rc(McfView v, int64_t s
     block_argmax<kPriceThreads>(key, arc);
     if (threadIdx.x == 0) {
         cand[blockIdx.x] = McfCand{key, arc};
+        write_candx(v, arc);
         // every lane has passed the gate above (the arg-max has a barrier): the flag may go down now
         if (INC && v.dirty && use_block != 1 && c->status == MCF_RUNNING) v.dirty->flag[blockIdx.x] = 0;
     }
@@ -418,6 +433,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_v(McfView v, int64_t sh
     block_argmax<kPriceThreads>(key, arc);
     if (threadIdx.x == 0) {
         cand[blockIdx.x] = McfCand{key, arc};
+        write_candx(v, arc);
         if (INC && v.dirty && c->status == MCF_RUNNING) v.dirty->flag[blockIdx.x] = 0;
     }
 }
@@ -429,6 +445,7 @@ __global__ __launch_bounds__(kPriceThreads) void k_price_v(McfView v, int64_t sh
 // atomics.  The pass lives in k_update below.
 constexpr int kRcupdThreads = 256;
 constexpr int kMaxRcupdBlocks = 1024;
+constexpr int kCandxBlocks = 8;   // workgroups of the dense update launches that keep the candidate cache current (2 048 entries)
 
 // ------------------------------------------------------------------ k_update = tree/potential apply + reduced-cost update in ONE launch
 // Resident-rc engines only.  The two halves touch disjoint data once T2 membership is tested
@@ -523,6 +540,30 @@ __device__ __forceinline__ void rcupd_pass(const McfView& v, const McfCtx& c, in
     }
 }
 
+// Candidate cache: every listed arc's reduced cost follows the potential shift of the re-hung subtree (+sigma when its tail
+// is inside T2, -sigma when its head is), and the leaving arc's entry takes its new state.  Membership against the OLD view,
+// like the reduced-cost patch; a single-node T2 whose node the pivot kernel named needs no look-up at all.
+__device__ __forceinline__ void candx_pass(const McfView& v, const McfCtx& c, int32_t tid, int32_t stride) {
+    if (!v.candx) return;
+    const bool bpl = MCF_HAS_BPL(v);
+    const int32_t a0 = c.t2_old, S = c.t2_size;
+    const int32_t* __restrict__ pold = c.cur ? v.posbuf[1] : v.posbuf[0];  // dense array: old positions
+    const bool one = bpl && c.pv_t2n == 1;
+    for (int32_t i = tid; i < v.ncandx; i += stride) {
+        McfCandX x = v.candx[i];
+        if (x.arc < 0) continue;
+        bool tin, hin;
+        if (one) { tin = x.tail == c.pv_t2node; hin = x.head == c.pv_t2node; }
+        else if (bpl) { tin = mcf_bpl_in_t2(v, c, x.tail); hin = mcf_bpl_in_t2(v, c, x.head); }
+        else { const int32_t pt = pold[x.tail], ph = pold[x.head]; tin = pt >= a0 && pt < a0 + S; hin = ph >= a0 && ph < a0 + S; }
+        const bool leave = (int32_t)(x.arc & 0xffffffff) == c.pv_leave;
+        if (tin == hin && !leave) continue;
+        if (tin != hin) x.rc += tin ? c.sigma : -c.sigma;
+        if (leave) x.state = c.pv_leave_state;
+        v.candx[i] = x;
+    }
+}
+
 // The two halves are independent, and each is a chain of dependent loads: different workgroups run them side
 // by side (the first `apply_blocks` the permutation, the others the reduced-cost patch) instead of one after the other.
 template <bool MARK>  // MARK: the handle prices incrementally, the patched arcs' blocks are flagged
@@ -532,10 +573,13 @@ __global__ __launch_bounds__(kRcupdThreads) void k_update(McfView g, int apply_b
     const McfCtx c = *v.ctx;  // uniform: scalar loads
     if (!c.apply) return;
     const int b = blockIdx.x;
+    const int xb = v.candx ? kCandxBlocks : 0;   // the last workgroups keep the candidate cache current
     if (b < apply_blocks) {
         apply_pass(v, c, (int64_t)b * kRcupdThreads + threadIdx.x, (int64_t)apply_blocks * kRcupdThreads);
+    } else if (b >= (int)gridDim.x - xb) {
+        candx_pass(v, c, (b - ((int)gridDim.x - xb)) * kRcupdThreads + (int)threadIdx.x, xb * kRcupdThreads);
     } else {
-        const int64_t rb = b - apply_blocks, nrb = (int64_t)gridDim.x - apply_blocks;
+        const int64_t rb = b - apply_blocks, nrb = (int64_t)gridDim.x - apply_blocks - xb;
         rcupd_pass(v, c, rb * (kRcupdThreads / 16) + (threadIdx.x >> 4), nrb * (kRcupdThreads / 16), threadIdx.x & 15);
     }
 }
@@ -671,6 +715,7 @@ __global__ __launch_bounds__(kBplThreads) void k_update_bpl(McfView g, int G) {
     if (!c.apply) return;
     McfView v = g;
     if (!MARK) v.dirty = nullptr;
+    if ((int32_t)blockIdx.x > G) { candx_pass(v, c, (int32_t)threadIdx.x, kBplThreads); return; }   // the candidate cache's workgroup
     const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t known0 = c.rebuild ? -1 : c.t2_blk, known1 = c.rebuild ? -1 : c.ins_blk;   // taken apart by the direct workgroup
     if (direct) {
@@ -768,6 +813,10 @@ struct PivotShared {
     McfCycle cy;
     McfScanAcc acc;
     int go;  // 0 = nothing to pivot on, 1 = the climb reached the join, 2 = the scan has to finish the cycle
+    // candidate cache: the winning entry (its index in the list, -1: none / not cached) and its record
+    int64_t win_arc;
+    int32_t win_idx;
+    McfCandX winx;
     McfHit hits[kHitsLds];
     int32_t path[2][kSmallPath], ppos[2][kSmallPath], pslot[2][kSmallPath];
     McfNode rec[2][kSmallPath];
@@ -777,9 +826,10 @@ static_assert(sizeof(McfCtx) % 4 == 0 && kCtxWords <= kPivotThreads, "control bl
 
 // From the chosen entering arc to the updated flows / tree records / apply descriptor.  `v.ctx` must point at
 // S.ctx; (key, arc) valid in thread 0; `priced` = arcs this pass evaluated (accounting).  All threads call it.
+// `cached`: S.win_idx / S.winx hold the winner's candidate record (candidate cache)
 template <int NT = kPivotThreads>   // NT: threads of the calling workgroup
 __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int64_t key, int64_t arc, int32_t rule,
-                                            int64_t priced) {
+                                            int64_t priced, bool cached = false) {
     const McfPaths gp = mcf_view_paths(v);                                                    // cycle scratch in global memory
     // ... and in LDS (dense array: a slot IS a position, one array serves both)
     const bool bpl = MCF_HAS_BPL(v);
@@ -789,7 +839,8 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
         McfCtx* c = v.ctx;
         if (c->pivots < c->max_pivots) c->arcs_priced += priced;  // whole-job accounting: the arcs of this pass over ALL shards
         int go = 0;
-        if (mcf_pivot_begin(v, key, arc, rule)) {
+        const bool have_wx = cached && arc >= 0 && S.win_idx >= 0;
+        if (mcf_pivot_begin(v, key, arc, rule, have_wx ? &S.winx : nullptr)) {
             MCF_PSTAMP(2);
             mcf_cycle_init(v, &S.cy);
             // sequential part: at most climb_budget dependent round trips.  Shallow end points (the depth gate) are climbed
@@ -818,21 +869,31 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
     __syncthreads();
     if (go && S.cy.small) mcf_pivot_finish(v, sp, threadIdx.x, NT);  // array updates, one path element per lane
     else mcf_pivot_finish(v, gp, threadIdx.x, NT);
+    // candidate cache: the entering arc's entry follows its new state (basic after a swap, the other bound after a flip);
+    // the leaving arc's entry, if it is listed, and every entry's reduced cost are the update pass's business
+    if (cached && threadIdx.x == 0 && S.win_idx >= 0 && S.ctx.stage != 0)
+        v.candx[S.win_idx].state = S.ctx.stage == 1 ? -S.ctx.pv_s : 0;
     MCF_PSTAMP(9);
 }
 
 template <bool MARK>  // MARK: the handle prices incrementally, the entering / leaving arc's blocks are flagged
+// `g_list`: the handle's own candidate list -- only for it does the candidate cache hold the records
 __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCand* __restrict__ cand, int ncand,
-                                                          int32_t rule, int have_sweep) {
+                                                          int32_t rule, int have_sweep, const McfCand* g_list) {
     __shared__ PivotShared S;
 #ifdef MCF_STAMPS
     if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = __builtin_amdgcn_s_memtime(); }
 #endif
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&S.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
-    // the first two candidates of every lane are in flight together with the control block (the grid leaves at most 2 048)
+    // the first two candidates of every lane are in flight together with the control block (the grid leaves at most 2 048);
+    // candidate cache (g.candx): the records instead -- they hold everything a minor iteration needs
+    const bool cached = g.candx != nullptr && rule == MCF_RULE_CANDIDATE_LIST && ncand <= 2 * kPivotThreads && cand == g_list;
     McfCand first = McfCand{0, -1}, second = McfCand{0, -1};
-    if ((int)threadIdx.x < ncand) first = cand[threadIdx.x];
-    if ((int)threadIdx.x + kPivotThreads < ncand) second = cand[threadIdx.x + kPivotThreads];
+    McfCandX x0, x1;
+    x0.arc = -1; x1.arc = -1; x0.rc = 0; x1.rc = 0; x0.state = 0; x1.state = 0; x0.tail = x0.head = x1.tail = x1.head = 0;
+    if ((int)threadIdx.x < ncand) { if (cached) x0 = g.candx[threadIdx.x]; else first = cand[threadIdx.x]; }
+    if ((int)threadIdx.x + kPivotThreads < ncand) { if (cached) x1 = g.candx[threadIdx.x + kPivotThreads]; else second = cand[threadIdx.x + kPivotThreads]; }
+    if (threadIdx.x == 0) S.win_idx = -1;
     __syncthreads();
     McfView v = g;
     v.ctx = &S.ctx;
@@ -853,7 +914,15 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     int64_t priced = minor ? ncand : v.m;
     if (threadIdx.x == 0 && rule == MCF_RULE_DEVEX_BLOCK && v.dx && S.ctx.num_blocks > 1)
         priced = mcf_devex_block_arcs(v.dx, (int32_t)S.ctx.block_index, S.ctx.block_granules);
-    if (minor && v.rcache && !v.rc_partial) {
+    if (cached) {
+        // keys straight from the records (a fresh sweep's record gives the sweep's key; an entry a clean incremental block
+        // kept, or one that pivots have touched since, gives what a sweep would find now)
+        const int64_t v0 = -(int64_t)x0.state * x0.rc, v1 = -(int64_t)x1.state * x1.rc;
+        const int64_t k0 = (x0.arc >= 0 && v0 > 0) ? mcf_dantzig_key(v, x0.arc & 0xffffffff, v0, x0.state) : 0;
+        const int64_t k1 = (x1.arc >= 0 && v1 > 0) ? mcf_dantzig_key(v, x1.arc & 0xffffffff, v1, x1.state) : 0;
+        if (mcf_cand_better(k0, x0.arc, key, arc)) { key = k0; arc = x0.arc; }
+        if (mcf_cand_better(k1, x1.arc, key, arc)) { key = k1; arc = x1.arc; }
+    } else if (minor && v.rcache && !v.rc_partial) {
         // re-pricing from the resident reduced costs: state and reduced cost of both listed arcs of a lane are requested
         // at once, unconditionally (a dead entry reads arc 0) -- ONE round trip for the whole list instead of a chain of
         // candidate -> state -> reduced cost per entry (measured at 2 048 entries: 5.6 us of a 17 us launch)
@@ -881,8 +950,16 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     } else {
         block_argmax<kPivotThreads>(key, arc);
     }
+    if (cached) {   // who won?  its lane hands the record over (two barriers: cheaper than looking the arc up again)
+        if (threadIdx.x == 0) S.win_arc = key > 0 ? arc : -1;
+        __syncthreads();
+        const int64_t wa = S.win_arc;
+        if (wa >= 0 && x0.arc == wa) { S.winx = x0; S.win_idx = (int32_t)threadIdx.x; }
+        else if (wa >= 0 && x1.arc == wa) { S.winx = x1; S.win_idx = (int32_t)threadIdx.x + kPivotThreads; }
+        __syncthreads();
+    }
     MCF_PSTAMP(1);
-    pivot_core(v, S, key, arc, rule, priced);
+    pivot_core(v, S, key, arc, rule, priced, cached);
     // publish the control block for the apply / pricing launches that follow (finish only reads it)
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&S.ctx)[threadIdx.x];
 #ifdef MCF_STAMPS
@@ -1153,7 +1230,10 @@ __global__ __launch_bounds__(kRcupdThreads) void k_rcupd(McfView g) {
 __global__ __launch_bounds__(kApplyThreads) void k_apply(McfView v) {
     const McfCtx c = *v.ctx;  // uniform: scalar loads
     if (!c.apply) return;
-    apply_pass(v, c, (int64_t)blockIdx.x * kApplyThreads + threadIdx.x, (int64_t)gridDim.x * kApplyThreads);
+    const int xb = v.candx ? kCandxBlocks : 0;   // (kApplyThreads == kRcupdThreads)
+    const int nb = (int)gridDim.x - xb;
+    if ((int)blockIdx.x >= nb) { candx_pass(v, c, ((int)blockIdx.x - nb) * kApplyThreads + (int)threadIdx.x, xb * kApplyThreads); return; }
+    apply_pass(v, c, (int64_t)blockIdx.x * kApplyThreads + threadIdx.x, (int64_t)nb * kApplyThreads);
 }
 
 // ------------------------------------------------------------------ two-lane cycle climb (LDS loop)
@@ -1545,6 +1625,7 @@ struct mcf_handle {
     McfSeg* d_seg = nullptr;
     McfCtx* d_ctx = nullptr;
     McfCand* d_cand = nullptr;
+    McfCandX* d_candx = nullptr;    // candidate cache (candidate-list rule, single GPU, grid path)
     McfCand* d_cand_aux = nullptr;  // scratch for mcf_price_once / mcf_time_pricing: the live list in d_cand must survive them
     McfCand* d_one = nullptr;
     McfCtx* h_ctx = nullptr;   // pinned
@@ -1804,8 +1885,11 @@ int upload_image(mcf_handle* h) {
     return MCF_OK;
 }
 
-void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, int use_block, McfCand* out = nullptr) {
+void launch_price(mcf_handle* h, hipStream_t s, const McfView& v_in, int32_t rule, int use_block, McfCand* out = nullptr) {
     int64_t* swept = out ? nullptr : h->d_swept;  // measurement / parity launches (own candidate buffer) are not accounted
+    McfView vx = v_in;
+    if (out) vx.candx = nullptr;   // ... and leave the live list's records alone
+    const McfView& v = vx;
     if (!out) out = h->d_cand;
     const dim3 grid(h->price_blocks), block(kPriceThreads);
     const int64_t z = 0;
@@ -1831,23 +1915,24 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v, int32_t rule, 
 }
 
 void launch_k_pivot(mcf_handle* h, hipStream_t s, const McfCand* cand, int ncand, int32_t rule, int have_sweep) {
-    if (h->view.dirty) hipLaunchKernelGGL(k_pivot<true>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep);
-    else hipLaunchKernelGGL(k_pivot<false>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep);
+    if (h->view.dirty) hipLaunchKernelGGL(k_pivot<true>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep, (const McfCand*)h->d_cand);
+    else hipLaunchKernelGGL(k_pivot<false>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep, (const McfCand*)h->d_cand);
 }
 
 void launch_apply(mcf_handle* h, hipStream_t s) {
     if (h->bpl) {  // blocked preorder list: block records, T2 move and reduced-cost patch in one launch
-        const dim3 grid(h->bpl_grid + 1), block(kBplThreads);   // (+1: the direct workgroup)
+        const dim3 grid(h->bpl_grid + 1 + (h->view.candx ? 1 : 0)), block(kBplThreads);   // (+1: the direct workgroup, +1: the candidate cache)
         if (!h->rcached) hipLaunchKernelGGL((k_update_bpl<false, false>), grid, block, 0, s, h->view, h->bpl_grid);
         else if (h->view.dirty) hipLaunchKernelGGL((k_update_bpl<true, true>), grid, block, 0, s, h->view, h->bpl_grid);
         else hipLaunchKernelGGL((k_update_bpl<false, true>), grid, block, 0, s, h->view, h->bpl_grid);
         return;
     }
+    const int xb = h->view.candx ? kCandxBlocks : 0;
     if (h->rcached) {  // tree/potential update and reduced-cost update in one launch
-        if (h->view.dirty) hipLaunchKernelGGL(k_update<true>, dim3(h->apply_blocks + h->rcupd_blocks), dim3(kRcupdThreads), 0, s, h->view, h->apply_blocks);
-        else hipLaunchKernelGGL(k_update<false>, dim3(h->apply_blocks + h->rcupd_blocks), dim3(kRcupdThreads), 0, s, h->view, h->apply_blocks);
+        if (h->view.dirty) hipLaunchKernelGGL(k_update<true>, dim3(h->apply_blocks + h->rcupd_blocks + xb), dim3(kRcupdThreads), 0, s, h->view, h->apply_blocks);
+        else hipLaunchKernelGGL(k_update<false>, dim3(h->apply_blocks + h->rcupd_blocks + xb), dim3(kRcupdThreads), 0, s, h->view, h->apply_blocks);
     } else {
-        hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks), dim3(kApplyThreads), 0, s, h->view);
+        hipLaunchKernelGGL(k_apply, dim3(h->apply_blocks + xb), dim3(kApplyThreads), 0, s, h->view);
     }
 }
 
@@ -1967,7 +2052,7 @@ void free_all(mcf_handle* h) {
     (void)hipFree(h->d_arcw); (void)hipFree(h->d_pi); (void)hipFree(h->d_node); (void)hipFree(h->d_order0); (void)hipFree(h->d_order1);
     (void)hipFree(h->d_path1); (void)hipFree(h->d_path2); (void)hipFree(h->d_ppos1); (void)hipFree(h->d_ppos2); (void)hipFree(h->d_rec1); (void)hipFree(h->d_rec2); (void)hipFree(h->d_seg); (void)hipFree(h->d_ctx); (void)hipFree(h->d_cand); (void)hipFree(h->d_cand_aux); (void)hipFree(h->d_one);
     (void)hipFree(h->d_pos0); (void)hipFree(h->d_pos1); (void)hipFree(h->d_psz0); (void)hipFree(h->d_psz1); (void)hipFree(h->d_reach); (void)hipFree(h->d_chg); (void)hipFree(h->d_dirty); (void)hipFree(h->d_swept); (void)hipFree(h->d_dx); (void)hipFree(h->d_full_tab);
-    (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj); (void)hipFree(h->d_vkey);
+    (void)hipFree(h->d_rcache); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj); (void)hipFree(h->d_vkey); (void)hipFree(h->d_candx);
     for (int a = 0; a < 2; ++a) { (void)hipFree(h->d_bmeta[a]); (void)hipFree(h->d_bext[a]); }
     if (h->h_ctx) pinned_give(reinterpret_cast<char*>(h->h_ctx));   // (h_one lives in the same slot)
     if (h->stream && h->stream_owned) (void)hipStreamDestroy(h->stream);
@@ -2163,7 +2248,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     }
     // position-space subtree sizes for the cycle scan: every handle but the LDS-resident ones
     const bool scan_ok = opt.cycle_scan >= 0 && im.n_nodes <= kScanMaxNodes && !h->small;  // -1: never scan
-    v.bmeta[0] = v.bmeta[1] = nullptr; v.bext[0] = v.bext[1] = nullptr; v.blk_shift = 0; v.blk_cap = 0; v.blk_pad = 0;
+    v.bmeta[0] = v.bmeta[1] = nullptr; v.bext[0] = v.bext[1] = nullptr; v.blk_shift = 0; v.blk_cap = 0; v.ncandx = 0; v.candx = nullptr;
     if (h->bpl) {
         // the two slot arenas (sizes; node ids are d_order0/1), the block records (two copies) and extents (one per arena),
         // and the scratch the scan spills flagged blocks to
@@ -2279,15 +2364,24 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         if ((e = hipMemcpy(h->d_dirty, &head, offsetof(McfDirty, flag), hipMemcpyHostToDevice)) != hipSuccess) return fail("copy dirty", e);
         v.dirty = h->d_dirty;
     }
+    // candidate cache: the grid path of the candidate-list rule on one GPU, keys that need nothing but the reduced cost
+    v.candx = nullptr; v.ncandx = 0;
+    if (opt.rule == MCF_RULE_CANDIDATE_LIST && h->shards == 1 && !h->small && !h->mid && !opt.profile && v.key_mode <= MCF_KEY_FORWARD_FIRST &&
+        h->price_blocks <= 2 * kPivotThreads && !std::getenv("MCF_NO_CANDX")) {
+        if ((e = dalloc(&h->d_candx, kMaxPriceBlocks)) != hipSuccess) return fail("hipMalloc candidate records", e);
+        if ((e = hipMemset(h->d_candx, 0xff, kMaxPriceBlocks * sizeof(McfCandX))) != hipSuccess) return fail("hipMemset candidate records", e);
+        v.candx = h->d_candx; v.ncandx = h->price_blocks;
+    }
     h->rc_able = h->rcached;
     {
-        // auto: candidate lists (one sweep per ~33 pivots) from an average |T2| of 384 nodes, Devex (one block per pivot) from
-        // 2 048; never for the Dantzig rule, whose every pivot sweeps all arcs, for shards (their driver owns the launches) or
-        // the persistent loops.  rc_drop: -1 = never, k > 0 = that threshold.
+        // auto: candidate lists (one sweep per ~33 pivots) on large instances (from 100 000 nodes: measured at 1 M / 16 M) from an
+        // average |T2| of 384 nodes; on request for Devex; never for the Dantzig rule, whose every pivot sweeps all arcs, for
+        // shards (their driver owns the launches) or the persistent loops.  rc_drop: -1 = never, k > 0 = that threshold.
         int64_t thr = 0;
         if (h->rcached && !h->mid && !h->small && h->shards == 1 && opt.key_mode == 0 && !opt.forward_first) {
             if (opt.rc_drop > 0) thr = opt.rc_drop;
-            else if (opt.rc_drop == 0) thr = opt.rule == MCF_RULE_CANDIDATE_LIST ? 384 : (opt.rule == MCF_RULE_DEVEX_BLOCK ? 2048 : 0);
+            else if (opt.rc_drop == 0) thr = (opt.rule == MCF_RULE_CANDIDATE_LIST && im.n_nodes >= 100000) ? 384 : 0;
+            if (opt.rule == MCF_RULE_DANTZIG_FULL) thr = 0;
         }
         if (const char* env = std::getenv("MCF_RC_DROP")) { const long vv = std::atol(env); thr = vv > 0 ? vv : 0; }   // A/B switch
         h->rc_drop_subtree = h->rcached && h->shards == 1 ? thr : 0;

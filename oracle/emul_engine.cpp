@@ -108,7 +108,7 @@ void bind(Emul& e) {
     for (int32_t b = 0; b < (im.n_nodes + MCF_REACH_BLOCK - 1) / MCF_REACH_BLOCK; ++b) mcf_reach_reindex_block(v, v.psz[0], b);
     v.bmeta[0] = v.bmeta[1] = nullptr;
     v.bext[0] = v.bext[1] = nullptr;
-    v.blk_shift = 0; v.blk_cap = 0; v.blk_pad = 0;
+    v.blk_shift = 0; v.blk_cap = 0; v.ncandx = 0; v.candx = nullptr;
     if (e.bpl_shift > 0) {
         // blocked preorder list: the same logical preorder in physical blocks (mcf_core.h); the arenas take the place of
         // the order / size arrays, loc[] that of the positions

@@ -39,7 +39,8 @@ eng.solve(max_pivots=200_000_000, progress=progress, progress_interval=250_000)
 res = eng.result()
 dt = time.time() - t0
 print(f"status={res.status} pivots={res.stats['pivots']} seconds={dt:.1f} pivots/s={res.stats['pivots'] / dt:.0f} objective={res.objective} "
-      f"artificial_flow={res.stats['artificial_flow']} degenerate={res.stats['degenerate']}", flush=True)
+      f"artificial_flow={res.stats['artificial_flow']} degenerate={res.stats['degenerate']} tree_blocks={res.stats['tree_blocks']} "
+      f"rebuilds={res.stats['tree_rebuilds']} rc_dropped_at={res.stats['rc_dropped_at']} moved/subtree={res.stats['nodes_moved'] / max(res.stats['subtree_nodes'], 1):.2f}", flush=True)
 if res.status == "optimal":
     from conftest import check_optimality
     check_optimality(inst, res.flow, res.potential)
