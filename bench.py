@@ -305,10 +305,31 @@ def spawn_ranks(n: int) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    return max(abs(rc) for rc in rcs)
+    # a rank that dies takes the others' collectives with it: poll, and end everybody as soon as one has failed
+    import threading
+
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in out_chunks if c).decode())
+    return 1 if failed else max(abs(rc) for rc in rcs)
 
 
 def batched_point(rule: int, instances: int = 1024, nodes: int = 256, arcs: int = 2048, label: str = "netgen_8_08a") -> dict:

@@ -280,7 +280,11 @@ struct McfBlkMeta {
 #define MCF_LOC_SLOT (MCF_LOC_ARENA - 1)
 #define MCF_EXT_FLAG (1 << 24)           // bext: a subtree that starts in the block shrank, rrel is due for re-indexing
 #define MCF_BLK_COPIES 2                 // copy blocks reserved per pivot (a block is cut at most at the hole T2 leaves and at the insertion point)
+#if defined(MCF_NO_BPL)   // A/B build: what do the blocked list's branches cost the dense paths?
+#define MCF_HAS_BPL(v) false
+#else
 #define MCF_HAS_BPL(v) ((v).bmeta[0] != nullptr)
+#endif
 
 // Raw views the core functions operate on (device pointers in the kernels,
 // host pointers in the emulation build).
@@ -359,6 +363,7 @@ struct McfView {
     // block's flag, and a full Dantzig sweep (also the candidate-list rule's) skips the blocks whose flag is down.
     // (one pointer only: the view travels in scalar registers, and 136 more bytes of it cost every kernel ~1.3 us)
     struct McfDirty* dirty;
+    const struct McfDirty* dirty_hdr;   // a copy of *dirty's header (nlb, lo, hi) that is cheaper to read (LDS in the pivot kernel), or nullptr
 };
 
 #define MCF_MAX_PRICE_BLOCKS 2048
@@ -483,7 +488,7 @@ MCF_HD int32_t mcf_price_block_of(const McfView& v, const McfDirty* d, int64_t e
 MCF_HD void mcf_mark_dirty(const McfView& v, int64_t e) {
     McfDirty* d = v.dirty;
     if (!d || e >= v.m) return;
-    const int32_t b = mcf_price_block_of(v, d, e);
+    const int32_t b = mcf_price_block_of(v, v.dirty_hdr ? v.dirty_hdr : d, e);
     if (b >= 0) d->flag[b] = 1;
 }
 
@@ -663,7 +668,10 @@ struct McfScanAcc {
 // in this slot (limit reached, no candidate, ...); the control block then already says why.
 // `wx`: the winner's candidate record when the caller has it (candidate cache): state, end points and reduced cost then
 // need no look-up, and the arc's capacity / flow load does not depend on anything else the cycle search fetches.
-MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule, const McfCandX* wx = nullptr) {
+// `cy` != null: the records and slots of the arc's end points are fetched here too -- together with the arc's capacity /
+// flow, before anything is stored -- and *cy is left as mcf_cycle_init would leave it (the caller then skips that call).
+MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule, const McfCandX* wx = nullptr,
+                            McfCycle* cy = nullptr) {
     McfCtx* c = v.ctx;
     c->apply = 0;
     c->stage = 0;
@@ -724,16 +732,35 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
         rc = (v.rcache && !v.rc_partial) ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
     }
 
-    c->pv_e = e; c->pv_s = s; c->pv_first = first; c->pv_second = second; c->pv_rc = rc;
+    // ---- loads first, all independent of each other: one round trip
     const McfArcW ae = v.arcw[e];  // one 16-byte load: capacity for the ratio test, flow for the store-only update
+    McfNode ru = McfNode{0, 0, 0, 0}, rw = McfNode{0, 0, 0, 0};
+    int32_t su = 0, sw = 0;
+    if (cy) { ru = v.node[first]; rw = v.node[second]; su = mcf_node_slot(v, c, first); sw = mcf_node_slot(v, c, second); }
+    int64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const bool adjp = MCF_HAS_BPL(v) && v.rcache;
+    if (adjp) {
+        // the re-hung subtree contains exactly one end point of the entering arc; when it is that node alone (most pivots of
+        // a large sparse instance) the update's reduced-cost patch can start from here instead of looking the node up
+        a0 = v.adj_off[first]; a1 = v.adj_off[first + 1];
+        a2 = v.adj_off[second]; a3 = v.adj_off[second + 1];
+    }
+    // ---- then the stores
+    c->pv_e = e; c->pv_s = s; c->pv_first = first; c->pv_second = second; c->pv_rc = rc;
     c->pv_cap = ae.cap;
     c->pv_flow = ae.flow;
     c->pv_t2n = 0;
-    if (MCF_HAS_BPL(v) && v.rcache) {
-        // the re-hung subtree contains exactly one end point of the entering arc; when it is that node alone (most pivots of
-        // a large sparse instance) the update's reduced-cost patch can start from here instead of looking the node up
-        c->pv_adj[0] = v.adj_off[first]; c->pv_adj[1] = v.adj_off[first + 1];
-        c->pv_adj[2] = v.adj_off[second]; c->pv_adj[3] = v.adj_off[second + 1];
+    if (adjp) { c->pv_adj[0] = a0; c->pv_adj[1] = a1; c->pv_adj[2] = a2; c->pv_adj[3] = a3; }
+    if (cy) {
+        cy->u = first; cy->w = second;
+        cy->ru = ru; cy->rw = rw;
+        cy->su = su; cy->sw = sw; cy->s0u = su; cy->s0w = sw;
+        cy->pu = su; cy->pw = sw; cy->p0u = su; cy->p0w = sw;   // dense array: the slot is the position; blocked list: resolved after the climb
+        cy->r0u = ru; cy->r0w = rw;
+        cy->small = 0;
+        cy->d1 = MCF_INF; cy->d2 = MCF_INF;
+        cy->k1 = -1; cy->k2 = -1;
+        cy->n1 = 0; cy->n2 = 0;
     }
     return true;
 }
@@ -750,8 +777,9 @@ MCF_HD void mcf_cycle_init(const McfView& v, McfCycle* cy) {
     cy->w = c->pv_second;
     cy->ru = v.node[cy->u];
     cy->rw = v.node[cy->w];
-    cy->pu = mcf_node_pos(v, c, cy->u, &cy->su);
-    cy->pw = mcf_node_pos(v, c, cy->w, &cy->sw);
+    cy->su = mcf_node_slot(v, c, cy->u);
+    cy->sw = mcf_node_slot(v, c, cy->w);
+    cy->pu = cy->su; cy->pw = cy->sw;   // dense array: the slot is the position; blocked list: resolved after the climb (mcf_pivot_climb)
     cy->r0u = cy->ru; cy->r0w = cy->rw;
     cy->p0u = cy->pu; cy->p0w = cy->pw;
     cy->s0u = cy->su; cy->s0w = cy->sw;
@@ -798,7 +826,8 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, const McfPaths& pb, McfCycle* cy, 
             if (r < d1) { d1 = r; k1 = n1; }
             pb.path1[n1] = u;
             pb.rec1[n1] = ru;
-            pb.slot1[n1] = su;   // (dense array: slot and position are the same word)
+            pb.slot1[n1] = su;
+            if (!bpl) pb.ppos1[n1] = su;   // dense array: the slot is the position (blocked list: resolved after the walk)
             if (pb.flow1) pb.flow1[n1] = au.flow;
             ++n1;
             u = ru.parent;
@@ -811,6 +840,7 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, const McfPaths& pb, McfCycle* cy, 
             pb.path2[n2] = w;
             pb.rec2[n2] = rw;
             pb.slot2[n2] = sw;
+            if (!bpl) pb.ppos2[n2] = sw;
             if (pb.flow2) pb.flow2[n2] = aw.flow;
             ++n2;
             w = rw.parent;
@@ -827,6 +857,9 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, const McfPaths& pb, McfCycle* cy, 
         for (int32_t i = n2_in; i < n2; ++i) { const int32_t sl = pb.slot2[i]; pb.ppos2[i] = bm[sl >> bs].base + (sl & bmask); }
         pu = bm[su >> bs].base + (su & bmask);
         pw = bm[sw >> bs].base + (sw & bmask);
+        // (the end points' own positions: the climb is always the first thing that runs on a fresh McfCycle)
+        cy->p0u = bm[cy->s0u >> bs].base + (cy->s0u & bmask);
+        cy->p0w = bm[cy->s0w >> bs].base + (cy->s0w & bmask);
     }
     cy->u = u; cy->w = w; cy->ru = ru; cy->rw = rw; cy->pu = pu; cy->pw = pw; cy->su = su; cy->sw = sw;
     cy->d1 = d1; cy->d2 = d2; cy->k1 = k1; cy->k2 = k2; cy->n1 = n1; cy->n2 = n2;

@@ -817,6 +817,7 @@ struct PivotShared {
     int64_t win_arc;
     int32_t win_idx;
     McfCandX winx;
+    int32_t dirty_hdr[20];   // incremental sweeps: nlb, lo[8], hi[8] of McfDirty (the marking's look-ups then stay in LDS)
     McfHit hits[kHitsLds];
     int32_t path[2][kSmallPath], ppos[2][kSmallPath], pslot[2][kSmallPath];
     McfNode rec[2][kSmallPath];
@@ -831,18 +832,15 @@ template <int NT = kPivotThreads>   // NT: threads of the calling workgroup
 __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int64_t key, int64_t arc, int32_t rule,
                                             int64_t priced, bool cached = false) {
     const McfPaths gp = mcf_view_paths(v);                                                    // cycle scratch in global memory
-    // ... and in LDS (dense array: a slot IS a position, one array serves both)
-    const bool bpl = MCF_HAS_BPL(v);
-    const McfPaths sp = McfPaths{S.path[0], S.path[1], S.rec[0], S.rec[1], S.ppos[0], S.ppos[1], S.flow[0], S.flow[1],
-                                 bpl ? S.pslot[0] : S.ppos[0], bpl ? S.pslot[1] : S.ppos[1]};
+    // ... and in LDS
+    const McfPaths sp = McfPaths{S.path[0], S.path[1], S.rec[0], S.rec[1], S.ppos[0], S.ppos[1], S.flow[0], S.flow[1], S.pslot[0], S.pslot[1]};
     if (threadIdx.x == 0) {
         McfCtx* c = v.ctx;
         if (c->pivots < c->max_pivots) c->arcs_priced += priced;  // whole-job accounting: the arcs of this pass over ALL shards
         int go = 0;
         const bool have_wx = cached && arc >= 0 && S.win_idx >= 0;
-        if (mcf_pivot_begin(v, key, arc, rule, have_wx ? &S.winx : nullptr)) {
+        if (mcf_pivot_begin(v, key, arc, rule, have_wx ? &S.winx : nullptr, &S.cy)) {   // (also what mcf_cycle_init would do)
             MCF_PSTAMP(2);
-            mcf_cycle_init(v, &S.cy);
             // sequential part: at most climb_budget dependent round trips.  Shallow end points (the depth gate) are climbed
             // outright: that path is short, so it is recorded in LDS, with the arcs' flows -- decide and finish then work
             // from LDS and the flow update is store-only, as after a scan.
@@ -894,10 +892,12 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     if ((int)threadIdx.x < ncand) { if (cached) x0 = g.candx[threadIdx.x]; else first = cand[threadIdx.x]; }
     if ((int)threadIdx.x + kPivotThreads < ncand) { if (cached) x1 = g.candx[threadIdx.x + kPivotThreads]; else second = cand[threadIdx.x + kPivotThreads]; }
     if (threadIdx.x == 0) S.win_idx = -1;
+    if (MARK && g.dirty && threadIdx.x >= 512 && threadIdx.x < 512 + 17) S.dirty_hdr[threadIdx.x - 512] = reinterpret_cast<const int32_t*>(g.dirty)[threadIdx.x - 512];
     __syncthreads();
     McfView v = g;
     v.ctx = &S.ctx;
     if (!MARK) v.dirty = nullptr;  // folds the marking away
+    else v.dirty_hdr = reinterpret_cast<const McfDirty*>(S.dirty_hdr);
     MCF_PSTAMP(0);
     // candidate-list rule: slots without a pricing launch in front (have_sweep == 0) can only run
     // minor iterations; once the list is exhausted they idle until the next slot that sweeps
@@ -1719,7 +1719,7 @@ hipError_t pinned_take(char** out) {
     if (g_pinned_free.empty()) {
         constexpr int kSlots = 256;
         char* block = nullptr;
-        const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&block), kSlots * kPinnedSlot, hipHostMallocDefault);
+        const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&block), kSlots * kPinnedSlot, hipHostMallocPortable);
         if (e != hipSuccess) return e;
         for (int i = kSlots - 1; i >= 0; --i) g_pinned_free.push_back(block + (size_t)i * kPinnedSlot);
     }
@@ -1740,13 +1740,14 @@ struct Stage {
     size_t used = 0;
     bool tried = false;
 };
-thread_local Stage t_stage;
+Stage g_stage;              // one per process (a per-thread one leaked 2 MiB of pinned memory for every host thread that ever created a handle)
+std::mutex g_stage_mu;      // held by upload_image from its first staged copy to the synchronisation that ends it
 
 hipError_t h2d(mcf_handle* h, void* dst, const void* src, size_t bytes) {
-    Stage& st = t_stage;
+    Stage& st = g_stage;
     if (!st.tried) {
         st.tried = true;
-        if (hipHostMalloc(reinterpret_cast<void**>(&st.base), kStageBytes, hipHostMallocDefault) != hipSuccess) { st.base = nullptr; (void)hipGetLastError(); }
+        if (hipHostMalloc(reinterpret_cast<void**>(&st.base), kStageBytes, hipHostMallocPortable) != hipSuccess) { st.base = nullptr; (void)hipGetLastError(); }
     }
     const size_t need = (bytes + 63) & ~(size_t)63;
     if (st.base && st.used + need <= kStageBytes) {
@@ -1760,7 +1761,8 @@ hipError_t h2d(mcf_handle* h, void* dst, const void* src, size_t bytes) {
 
 int upload_image(mcf_handle* h) {
     const McfHostImage& im = h->im;
-    t_stage.used = 0;   // (everything staged below is synchronised before this function returns)
+    std::lock_guard<std::mutex> stage_lock(g_stage_mu);
+    g_stage.used = 0;   // (everything staged below is synchronised before this function returns)
     if (h->rc_dropped) {   // a fresh start keeps the reduced costs resident again
         h->rc_dropped = false;
         h->rcached = true;
@@ -2233,7 +2235,8 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
             // (the limit is a property of the kernel, not of the handle: it only ever grows, so that handles of different
             //  sizes can be alive together -- and share one batched launch)
             static std::mutex lds_mu;
-            static int lds_limit = 0;
+            static int lds_limits[64] = {0};   // per device: the attribute belongs to the device's copy of the function
+            int& lds_limit = lds_limits[h->device & 63];
             std::lock_guard<std::mutex> lock(lds_mu);
             hipError_t fe = hipSuccess;
             if ((int)L.total > lds_limit) {
@@ -2614,14 +2617,16 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
     std::stable_partition(mid_jobs.begin(), mid_jobs.end(), [](const MidJob& J) { return J.rule != MCF_RULE_CANDIDATE_LIST; });
     size_t n_listing = 0;
     for (const MidJob& J : mid_jobs) n_listing += J.rule == MCF_RULE_CANDIDATE_LIST ? 1 : 0;
+    // job arrays and the two timing events come from a per-device pool that only ever grows (a call used to pay two
+    // hipMalloc / hipFree pairs and two event creations); the pool's lock also serialises concurrent batches on a device
+    struct BatchPool { void* small = nullptr; size_t small_bytes = 0; void* mid = nullptr; size_t mid_bytes = 0; hipEvent_t ev[2] = {nullptr, nullptr}; };
+    static std::mutex pool_mu;
+    static BatchPool pools[64];
+    std::lock_guard<std::mutex> pool_lock(pool_mu);
+    BatchPool& pool = pools[h0->device & 63];
     SmallJob* d_small = nullptr;
     MidJob* d_mid = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    auto cleanup = [&]() {
-        if (d_small) (void)hipFree(d_small);
-        if (d_mid) (void)hipFree(d_mid);
-        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-    };
+    auto cleanup = [&]() {};   // (nothing is owned by the call any more)
     auto bail = [&](const char* what, hipError_t e) {
         h0->err = std::string(what) + ": " + hipGetErrorString(e);
         cleanup();
@@ -2629,15 +2634,26 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
     };
     hipError_t e;
     hipStream_t s = h0->stream;
+    auto grow = [&](void** buf, size_t* have, size_t need) -> hipError_t {
+        if (need <= *have) return hipSuccess;
+        if (*buf) (void)hipFree(*buf);
+        *buf = nullptr; *have = 0;
+        const hipError_t ge = hipMalloc(buf, need * 2);
+        if (ge == hipSuccess) *have = need * 2;
+        return ge;
+    };
     if (!small_jobs.empty()) {
-        if ((e = hipMalloc(reinterpret_cast<void**>(&d_small), small_jobs.size() * sizeof(SmallJob))) != hipSuccess) return bail("hipMalloc jobs", e);
+        if ((e = grow(&pool.small, &pool.small_bytes, small_jobs.size() * sizeof(SmallJob))) != hipSuccess) return bail("hipMalloc jobs", e);
+        d_small = static_cast<SmallJob*>(pool.small);
         if ((e = hipMemcpyAsync(d_small, small_jobs.data(), small_jobs.size() * sizeof(SmallJob), hipMemcpyHostToDevice, s)) != hipSuccess) return bail("hipMemcpy jobs", e);
     }
     if (!mid_jobs.empty()) {
-        if ((e = hipMalloc(reinterpret_cast<void**>(&d_mid), mid_jobs.size() * sizeof(MidJob))) != hipSuccess) return bail("hipMalloc jobs", e);
+        if ((e = grow(&pool.mid, &pool.mid_bytes, mid_jobs.size() * sizeof(MidJob))) != hipSuccess) return bail("hipMalloc jobs", e);
+        d_mid = static_cast<MidJob*>(pool.mid);
         if ((e = hipMemcpyAsync(d_mid, mid_jobs.data(), mid_jobs.size() * sizeof(MidJob), hipMemcpyHostToDevice, s)) != hipSuccess) return bail("hipMemcpy jobs", e);
     }
-    if ((e = hipEventCreate(&ev[0])) != hipSuccess || (e = hipEventCreate(&ev[1])) != hipSuccess) return bail("hipEventCreate", e);
+    if (!pool.ev[0] && ((e = hipEventCreate(&pool.ev[0])) != hipSuccess || (e = hipEventCreate(&pool.ev[1])) != hipSuccess)) return bail("hipEventCreate", e);
+    hipEvent_t* ev = pool.ev;
     if ((e = hipEventRecord(ev[0], s)) != hipSuccess) return bail("hipEventRecord", e);
     if (!small_jobs.empty())
         hipLaunchKernelGGL(k_solve_small_batch, dim3((unsigned)small_jobs.size()), dim3(kSmallThreads), lds, s, (const SmallJob*)d_small);
@@ -2661,9 +2677,27 @@ int mcf_solve_batch(mcf_handle* const* handles, int32_t count, const int64_t* ma
         else if (n_list) hipLaunchKernelGGL((k_solve_mid_batch<512, true>), dim3(n_list), dim3(512), 0, s, lists);
     }
     if ((e = hipGetLastError()) != hipSuccess) return bail("mcf_solve_batch launch", e);
-    if ((e = hipEventRecord(ev[1], s)) != hipSuccess) return bail("hipEventRecord", e);
     // (every workgroup writes its final control block straight into its handle's pinned host copy: nothing to read back)
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail("hipStreamSynchronize", e);
+    // A persistent-loop launch runs at most 2^22 loop iterations per job: a job that is still RUNNING below its budget
+    // (large mid_loop = 1 instances) goes round again, like mcf_solve's loop, instead of coming back as "iteration limit".
+    for (int round = 0; round < 4096 && !mid_jobs.empty(); ++round) {
+        std::vector<MidJob> again_plain, again_list;
+        for (const MidJob& J : mid_jobs) {
+            const McfCtx* hc = J.host_ctx;
+            if (hc->status == MCF_RUNNING && hc->pivots < J.cap) (J.rule == MCF_RULE_CANDIDATE_LIST ? again_list : again_plain).push_back(J);
+        }
+        if (again_plain.empty() && again_list.empty()) break;
+        std::vector<MidJob> again(again_plain);
+        again.insert(again.end(), again_list.begin(), again_list.end());
+        if ((e = hipMemcpyAsync(d_mid, again.data(), again.size() * sizeof(MidJob), hipMemcpyHostToDevice, s)) != hipSuccess) return bail("hipMemcpy jobs", e);
+        if (!again_plain.empty()) hipLaunchKernelGGL((k_solve_mid_batch<1024, false>), dim3((unsigned)again_plain.size()), dim3(1024), 0, s, (const MidJob*)d_mid);
+        if (!again_list.empty()) hipLaunchKernelGGL((k_solve_mid_batch<1024, true>), dim3((unsigned)again_list.size()), dim3(1024), 0, s, (const MidJob*)(d_mid + again_plain.size()));
+        if ((e = hipGetLastError()) != hipSuccess) return bail("mcf_solve_batch relaunch", e);
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail("hipStreamSynchronize", e);
+    }
+    if ((e = hipEventRecord(ev[1], s)) != hipSuccess) return bail("hipEventRecord", e);
+    if ((e = hipEventSynchronize(ev[1])) != hipSuccess) return bail("hipEventSynchronize", e);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
     if (kernel_ms) *kernel_ms = ms;
@@ -2755,6 +2789,7 @@ int mcf_price_once(mcf_handle* h, int32_t rule, int64_t start, int64_t end, int6
     // price even when the solve has finished: temporarily view the control block as running
     McfView v = h->view;
     v.dirty = nullptr;  // a parity hook prices everything and leaves the flags alone
+    v.candx = nullptr;  // ... and the live list's records
     if (rule == MCF_RULE_DEVEX_BLOCK) v.weight = h->d_weight;
     HIP_TRY(h, hipMemcpyAsync(h->h_ctx, h->d_ctx, sizeof(McfCtx), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2879,6 +2914,7 @@ int mcf_time_pricing(mcf_handle* h, int32_t rule, int32_t reps, double* ms_per_l
     HIP_TRY(h, hipSetDevice(h->device));
     McfView v = h->view;
     v.dirty = nullptr;  // timed sweeps are full sweeps
+    v.candx = nullptr;  // (and leave the live list's records alone)
     if (rule == MCF_RULE_DEVEX_BLOCK) v.weight = h->d_weight;
     HIP_TRY(h, hipMemcpyAsync(h->h_ctx, h->d_ctx, sizeof(McfCtx), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -306,7 +306,25 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         ready = torch.tensor([1.0 if run is not None else 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(ready, op=dist.ReduceOp.MIN)
         if ready.item() == 1.0:
-            b = run.run(before=fence, after=fence)
+            # a rank whose batch fails must still reach both fences and the vote, or the others wait for it forever
+            b, fenced = None, [0]
+
+            def counted_fence():
+                fenced[0] += 1
+                fence()
+
+            try:
+                b = run.run(before=counted_fence, after=counted_fence)
+            except Exception as exc:  # noqa: BLE001
+                err = f"{type(exc).__name__}: {exc}"
+                while fenced[0] < 2:
+                    counted_fence()
+            good = torch.tensor([1.0 if b is not None else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            if good.item() != 1.0:
+                b = None
+                line["batched_point_error"] = err or "another rank's batched solve failed"
+        if ready.item() == 1.0 and b is not None:
             agg = torch.tensor([b["wall_s"], float(b["pivots"]), float(b["arcs_priced"]), 1.0 if b["all_optimal"] else 0.0],
                                dtype=torch.float64, device="cuda")
             tmax = agg[:1].clone()
@@ -319,7 +337,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
                 "pivots": int(agg[1].item()), "seconds": secs, "pivots_per_sec": float(agg[1].item()) / secs,
                 "value": float(agg[2].item()) / secs, "unit": "arcs/s", "solves_per_sec": per_rank * world / secs,
                 "all_optimal": bool(agg[3].item() == world)}
-        else:
+        elif ready.item() != 1.0:
             line["batched_point_error"] = err or "another rank could not create its handles"
         if run is not None:
             run.close()

@@ -217,6 +217,11 @@ class NetworkSimplex:
         special = entering_rule_options(self.network_structure, self.flat.node_ids, self.flat.tail, self.flat.head, self.flat.supply,
                                         unit=self.flat.flow_scale)
         if special is not None:
+            # the reference tries the specialised scan first and falls back to the configured strategy when it finds nothing
+            # (simplex.py:1060-1064); here the specialised rule IS a key variant of one sweep, so it replaces the strategy
+            # for the whole solve -- status and objective are the same, iteration counts need not be
+            if self.options.explicit_pricing_strategy and strategy != "dantzig":
+                self.logger.info(f"pricing_strategy={strategy!r} is overridden by the specialised rule of this network class")
             self.pricing_rule = special.pop("rule")
             self.logger.info(f"Using specialized pivot strategy for {self.network_structure.network_type.value}")
         bs = self.options.block_size

@@ -1,3 +1,5 @@
+#!/bin/bash
+# PMC passes (FETCH_SIZE / WRITE_SIZE, one counter per run, --kernel-trace only) for the sweep workloads; outputs under gpurun_out/final/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
 mkdir -p $O
