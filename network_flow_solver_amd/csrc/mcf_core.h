@@ -670,8 +670,9 @@ struct McfScanAcc {
 // need no look-up, and the arc's capacity / flow load does not depend on anything else the cycle search fetches.
 // `cy` != null: the records and slots of the arc's end points are fetched here too -- together with the arc's capacity /
 // flow, before anything is stored -- and *cy is left as mcf_cycle_init would leave it (the caller then skips that call).
-MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule, const McfCandX* wx = nullptr,
-                            McfCycle* cy = nullptr) {
+// (a compile-time switch, not a null test: with a run-time one the two node records took a detour through private memory)
+template <bool WITH_CY>
+MCF_HD bool mcf_pivot_begin_t(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule, const McfCandX* wx, McfCycle* cy) {
     McfCtx* c = v.ctx;
     c->apply = 0;
     c->stage = 0;
@@ -719,24 +720,28 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
     const int32_t e = (int32_t)(best_arc & 0xffffffff);  // engine index (low word of the packed id)
     int32_t s, first, second;
     int64_t rc;
+    // ---- everything that needs only e, requested together: one round trip
+    const McfArcW ae = v.arcw[e];  // capacity for the ratio test, flow for the store-only update
     if (wx) {
         s = wx->state;
         first = s > 0 ? wx->tail : wx->head;
         second = s > 0 ? wx->head : wx->tail;
         rc = wx->rc;
     } else {
+        // both end points are fetched whatever the state says (a select between two LOADED values, not a load from a selected
+        // address, which would have to wait for the state); so is the resident reduced cost
+        const bool resident = v.rcache && !v.rc_partial;
+        const int32_t te = v.tail[e], he = v.head[e];
         s = v.state[e];  // +1: flow rises from 0; -1: flow falls from cap
-        first = s > 0 ? v.tail[e] : v.head[e];
-        second = s > 0 ? v.head[e] : v.tail[e];
+        int64_t rcv = 0;
+        if (resident) rcv = v.rcache[e];
+        first = s > 0 ? te : he;
+        second = s > 0 ? he : te;
         // exact reduced cost of the entering arc (the Devex key is a merit, not a violation)
-        rc = (v.rcache && !v.rc_partial) ? v.rcache[e] : (int64_t)v.cost[e] + v.pi[v.tail[e]] - v.pi[v.head[e]];
+        rc = resident ? rcv : (int64_t)v.cost[e] + v.pi[te] - v.pi[he];
     }
 
-    // ---- loads first, all independent of each other: one round trip
-    const McfArcW ae = v.arcw[e];  // one 16-byte load: capacity for the ratio test, flow for the store-only update
-    McfNode ru = McfNode{0, 0, 0, 0}, rw = McfNode{0, 0, 0, 0};
-    int32_t su = 0, sw = 0;
-    if (cy) { ru = v.node[first]; rw = v.node[second]; su = mcf_node_slot(v, c, first); sw = mcf_node_slot(v, c, second); }
+    // ---- then what hangs on the end points, all independent of each other: one more round trip
     int64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const bool adjp = MCF_HAS_BPL(v) && v.rcache;
     if (adjp) {
@@ -745,24 +750,31 @@ MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc
         a0 = v.adj_off[first]; a1 = v.adj_off[first + 1];
         a2 = v.adj_off[second]; a3 = v.adj_off[second + 1];
     }
+    if (WITH_CY) {
+        // (records in consts that every store below reads: copied through a mutable temporary they took a detour
+        //  through private memory)
+        const McfNode ru = v.node[first], rw = v.node[second];
+        const int32_t su = mcf_node_slot(v, c, first), sw = mcf_node_slot(v, c, second);
+        cy->u = first; cy->w = second;
+        cy->ru = ru; cy->rw = rw;
+        cy->r0u = ru; cy->r0w = rw;
+        cy->su = su; cy->sw = sw; cy->s0u = su; cy->s0w = sw;
+        cy->pu = su; cy->pw = sw; cy->p0u = su; cy->p0w = sw;   // dense array: the slot is the position; blocked list: resolved after the climb
+        cy->small = 0;
+        cy->d1 = MCF_INF; cy->d2 = MCF_INF;
+        cy->k1 = -1; cy->k2 = -1;
+        cy->n1 = 0; cy->n2 = 0;
+    }
     // ---- then the stores
     c->pv_e = e; c->pv_s = s; c->pv_first = first; c->pv_second = second; c->pv_rc = rc;
     c->pv_cap = ae.cap;
     c->pv_flow = ae.flow;
     c->pv_t2n = 0;
     if (adjp) { c->pv_adj[0] = a0; c->pv_adj[1] = a1; c->pv_adj[2] = a2; c->pv_adj[3] = a3; }
-    if (cy) {
-        cy->u = first; cy->w = second;
-        cy->ru = ru; cy->rw = rw;
-        cy->su = su; cy->sw = sw; cy->s0u = su; cy->s0w = sw;
-        cy->pu = su; cy->pw = sw; cy->p0u = su; cy->p0w = sw;   // dense array: the slot is the position; blocked list: resolved after the climb
-        cy->r0u = ru; cy->r0w = rw;
-        cy->small = 0;
-        cy->d1 = MCF_INF; cy->d2 = MCF_INF;
-        cy->k1 = -1; cy->k2 = -1;
-        cy->n1 = 0; cy->n2 = 0;
-    }
     return true;
+}
+MCF_HD bool mcf_pivot_begin(const McfView& v, int64_t best_key, int64_t best_arc, int32_t rule) {
+    return mcf_pivot_begin_t<false>(v, best_key, best_arc, rule, nullptr, nullptr);
 }
 
 // Step 2a (one lane): the cycle by pointer chasing, at most `budget` round trips.

@@ -839,7 +839,7 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
         if (c->pivots < c->max_pivots) c->arcs_priced += priced;  // whole-job accounting: the arcs of this pass over ALL shards
         int go = 0;
         const bool have_wx = cached && arc >= 0 && S.win_idx >= 0;
-        if (mcf_pivot_begin(v, key, arc, rule, have_wx ? &S.winx : nullptr, &S.cy)) {   // (also what mcf_cycle_init would do)
+        if (mcf_pivot_begin_t<true>(v, key, arc, rule, have_wx ? &S.winx : nullptr, &S.cy)) {   // (also what mcf_cycle_init would do)
             MCF_PSTAMP(2);
             // sequential part: at most climb_budget dependent round trips.  Shallow end points (the depth gate) are climbed
             // outright: that path is short, so it is recorded in LDS, with the arcs' flows -- decide and finish then work
@@ -874,8 +874,10 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
     MCF_PSTAMP(9);
 }
 
-template <bool MARK>  // MARK: the handle prices incrementally, the entering / leaving arc's blocks are flagged
+// MARK: the handle prices incrementally, the entering / leaving arc's blocks are flagged.  BPL: the tree lives in the blocked
+// preorder list (a dense-array handle's instantiation folds every branch of it away: they cost the dense path ~4 %).
 // `g_list`: the handle's own candidate list -- only for it does the candidate cache hold the records
+template <bool MARK, bool BPL>
 __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCand* __restrict__ cand, int ncand,
                                                           int32_t rule, int have_sweep, const McfCand* g_list) {
     __shared__ PivotShared S;
@@ -898,6 +900,7 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     v.ctx = &S.ctx;
     if (!MARK) v.dirty = nullptr;  // folds the marking away
     else v.dirty_hdr = reinterpret_cast<const McfDirty*>(S.dirty_hdr);
+    if (!BPL) { v.bmeta[0] = nullptr; v.bmeta[1] = nullptr; }  // folds the blocked list away
     MCF_PSTAMP(0);
     // candidate-list rule: slots without a pricing launch in front (have_sweep == 0) can only run
     // minor iterations; once the list is exhausted they idle until the next slot that sweeps
@@ -1917,8 +1920,15 @@ void launch_price(mcf_handle* h, hipStream_t s, const McfView& v_in, int32_t rul
 }
 
 void launch_k_pivot(mcf_handle* h, hipStream_t s, const McfCand* cand, int ncand, int32_t rule, int have_sweep) {
-    if (h->view.dirty) hipLaunchKernelGGL(k_pivot<true>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep, (const McfCand*)h->d_cand);
-    else hipLaunchKernelGGL(k_pivot<false>, dim3(1), dim3(kPivotThreads), 0, s, h->view, cand, ncand, rule, have_sweep, (const McfCand*)h->d_cand);
+    const McfCand* own = h->d_cand;
+    const dim3 one(1), block(kPivotThreads);
+    if (h->view.dirty) {
+        if (h->bpl) hipLaunchKernelGGL((k_pivot<true, true>), one, block, 0, s, h->view, cand, ncand, rule, have_sweep, own);
+        else hipLaunchKernelGGL((k_pivot<true, false>), one, block, 0, s, h->view, cand, ncand, rule, have_sweep, own);
+    } else {
+        if (h->bpl) hipLaunchKernelGGL((k_pivot<false, true>), one, block, 0, s, h->view, cand, ncand, rule, have_sweep, own);
+        else hipLaunchKernelGGL((k_pivot<false, false>), one, block, 0, s, h->view, cand, ncand, rule, have_sweep, own);
+    }
 }
 
 void launch_apply(mcf_handle* h, hipStream_t s) {
