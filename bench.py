@@ -213,7 +213,8 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
         survey = (17 if rule == 1 else 13) * per_pass + 8 * (inst.n + 1)
         out["roofline"] = {
             "kernel": kname, "bound": "hbm", "workload": out["workload"],
-            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": min(achieved / HBM_PEAK_GBPS, 1.0),
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "frac_over_1": bool(achieved > HBM_PEAK_GBPS),   # never clamped: a fraction above 1 means the byte count or the timing is wrong
             "traffic": traffic, "traffic_source": src,
             "traffic_GBps": (traffic / (sweep_ms * 1e-3) / 1e9) if traffic else None,
             "traffic_frac_of_peak": (traffic / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,

@@ -250,25 +250,61 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
         arcs = eng.eng.stats()["arcs_priced"] - a0          # whole-job accounting: every pass counts the arcs of ALL shards
         sweep_ms = eng.eng.time_pricing(reps=20)
         shard_arcs = inst.m // world
-        # the kernel that runs is the resident-reduced-cost sweep over the rank's shard: 8 B rc + 1 B state per arc
-        # (+ 4 B Devex weight); SURVEY 8d's gather figure (13 B/arc + 8 B/node) is kept beside it for comparison
-        per_arc = 13 if rule == 1 else 9
-        bytes_per_launch = per_arc * shard_arcs
+        # The sweep kernel this rank's handle launches and its compulsory bytes come from the engine itself
+        # (mcf_stats.price_bytes / sweep_variant / pricing_mode), exactly as in bench.py's single-GPU leg: a sharded
+        # full-sweep Dantzig handle from 4 M arcs on sweeps 4-byte key codes (k_price_v), not 9-byte reduced costs.
+        st = eng.eng.stats()
+        variant, mode = int(st.get("sweep_variant", 0)), int(st.get("pricing_mode", 1))
+        bytes_per_launch = float(st["price_bytes"])
+        per_arc = bytes_per_launch / max(shard_arcs, 1)
+        if mode == 1 and rule != 1 and (variant & 1):
+            kname = f"k_price_v<{'true' if variant & 4 else 'false'}, {'true' if variant & 2 else 'false'}> (per-rank shard)"
+        elif mode == 1:
+            kname = f"k_price_rc<{1 if rule == 1 else 0},false,{'true' if variant & 4 else 'false'}> (per-rank shard)"
+        else:
+            kname = f"k_price<{1 if rule == 1 else 0},false> (per-rank shard)"
         achieved = bytes_per_launch / (sweep_ms * 1e-3) / 1e9
+        frac = achieved / hbm_peak_gbps
+        # where a pivot's time goes on this rank: the sweep (kernel duration above), the collective (a timed loop of the very
+        # all-gather the pivot loop issues), and what is left of the measured time per pivot = pivot + update kernels + gaps
+        coll_ms = None
+        try:
+            list_len, minor_cap = loop.listing if loop.listing is not None else (1, 0)
+            buf = torch.zeros(2 * list_len, dtype=torch.int64, device="cuda")
+            out = torch.zeros(world * buf.numel(), dtype=torch.int64, device="cuda")
+            dist.all_gather_into_tensor(out, buf)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            for _ in range(50):
+                dist.all_gather_into_tensor(out, buf)
+            torch.cuda.synchronize()
+            coll_ms = 1e3 * (time.perf_counter() - tc) / 50
+        except Exception:  # noqa: BLE001  (gloo rehearsals have no CUDA tensors)
+            coll_ms = None
+        per_pivot_ms = 1e3 * dt / max(pivots, 1)
+        sweeps_per_pivot = 1.0 if loop.listing is None else 1.0 / (loop.listing[1] + 1)
+        phases = {"sweep_ms_per_launch": sweep_ms, "sweeps_per_pivot": sweeps_per_pivot,
+                  "collective_ms_per_call": coll_ms, "collectives_per_pivot": sweeps_per_pivot if rule == 2 else 1.0,
+                  "ms_per_pivot": per_pivot_ms,
+                  "pivot_and_update_ms_per_pivot": per_pivot_ms - sweeps_per_pivot * sweep_ms - (coll_ms or 0.0) * (sweeps_per_pivot if rule == 2 else 1.0),
+                  "note": "replicated on every rank: the pivot kernel and the tree update; divided by the ranks: the sweep and, for the "
+                          "Dantzig / candidate-list rules, the reduced-cost patch"}
         eng.close()
         return {"workload": f"{inst.name}: {inst.n} nodes / {inst.m} arcs, {shard_arcs} arcs per GPU", "pivots": pivots,
                 "seconds": dt, "pivots_per_sec": pivots / dt,
                 "arcs_priced_per_sec": arcs / dt,
-                "ms_per_step": 1e3 * dt / max(pivots, 1), "completed": status == 2,
+                "ms_per_step": per_pivot_ms, "completed": status == 2,
                 "pivot_loop": "captured graph" if loop.graph is not None else "eager", "graph_error": loop.graph_error,
-                "roofline": {"kernel": f"k_price_rc<{1 if rule == 1 else 0},false,false> (per-rank shard)", "bound": "hbm",
+                "phases": phases,
+                "roofline": {"kernel": kname, "bound": "hbm",
                              "achieved": achieved, "peak": hbm_peak_gbps, "unit": "GB/s",
-                             "frac": min(achieved / hbm_peak_gbps, 1.0), "traffic": None,
-                             "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": sweep_ms,
+                             "frac": frac, "frac_over_1": bool(frac > 1.0), "traffic": None,
+                             "bytes_per_launch": int(bytes_per_launch), "bytes_per_arc": per_arc, "ms_per_launch": sweep_ms,
                              "working_set_fits_infinity_cache": bool(bytes_per_launch < 256 * 2 ** 20),
                              "survey_8d": {"bytes_per_launch": int((17 if rule == 1 else 13) * shard_arcs + 8 * (inst.n + 1))},
-                             "note": "back-to-back launches between two HIP events on the engine's stream; traffic: no PMC "
-                                     "pass exists for the sharded sweep (the 1-GPU passes are in profiles/pmc_traffic.json)"}}
+                             "note": "back-to-back launches between two HIP events on the engine's stream; kernel and bytes from "
+                                     "mcf_stats (price_bytes, sweep_variant); traffic: no PMC pass exists for the sharded sweep "
+                                     "(the 1-GPU passes are in profiles/pmc_traffic.json)"}}
 
     head = measure(workload, args.steps, args.warmup)
     line = {
@@ -280,7 +316,7 @@ def bench_main(args, workloads, hbm_peak_gbps: float) -> None:
                    "step": "one pivot (sharded price + 16 B all-gather + replicated tree/potential update)",
                    "parallelism": f"arc-sharded x{world}, replicated tree, 1 RCCL all-gather per pivot",
                    "pivot_loop": head["pivot_loop"], "graph_error": head["graph_error"]},
-        "roofline": head["roofline"],
+        "roofline": head["roofline"], "phases": head["phases"],
     }
     if not args.no_hbm_point and workload == "netgen_8_08a" and not strong:
         big = measure("netgen_8_18a" if "netgen_8_18a" in workloads else "netgen_8_16a", min(args.steps, 200), min(args.warmup, 20))

@@ -267,3 +267,49 @@ def test_entering_rule_options_follow_the_reference_dispatch():
     assert entering_rule_options(NetworkStructure(NetworkType.ASSIGNMENT, True), ids, tail, head, supply)["key_mode"] == e.KEY_FORWARD_FIRST
     assert entering_rule_options(NetworkStructure(NetworkType.TRANSPORTATION, True), ids, tail, head, supply) == {"rule": e.RULE_DANTZIG}
     assert entering_rule_options(NetworkStructure(NetworkType.GENERAL, False), ids, tail, head, supply) is None
+
+
+# ------------------------------------------------------------------ blocked preorder list (mcf_core.h) == dense preorder array
+def _layout(shift: int, pool: int) -> int:
+    """rule bits of oracle.emul_solve: 16-19 log2 of the block size, 20-31 the spare blocks (1 = none, k = k - 1, 0 = auto)."""
+    return (shift << 16) | (pool << 20)
+
+
+@pytest.mark.parametrize("rule", [0, 1, 2], ids=["dantzig", "devex_block", "candidate_list"])
+@pytest.mark.parametrize("shift,pool", [(2, 0), (2, 1), (3, 5), (4, 0), (6, 0), (6, 1)], ids=lambda x: str(x))
+def test_blocked_preorder_list_equals_dense_array(rule, shift, pool):
+    """The tree's logical preorder kept in physical blocks with a logical base each (O(subtree + block) element moves per
+    basis swap instead of a shift of everything between the subtree's old and new place; replaces the per-pivot BFS
+    rebuild basis.py:82-125) is the SAME logical preorder: pivots, flows, potentials, order, positions, sizes and depths
+    equal the dense array's for every block size, with a generous pool, a tiny one (frequent dense rewrites into the other
+    arena) and none at all (a rewrite on every pivot), by climb and by scan."""
+    from network_flow_solver_amd import generators
+
+    cases = [load_synthetic()[0][1], load_synthetic()[4][1], generators.goto_style(12, 12, seed=4), generators.gridgen_style(16, 16, seed=3)]
+    for inst in cases:
+        for cb in (0, -1):
+            ref = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, climb_budget=cb)
+            got = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule | _layout(shift, pool), climb_budget=cb)
+            assert got["status"] == ref["status"] == "optimal" and got["objective"] == ref["objective"] and got["pivots"] == ref["pivots"]
+            for key in ("flow", "potential", "parent", "pred_arc", "size", "pos", "order", "depth", "psize"):
+                assert np.array_equal(got[key], ref[key]), key
+            check_tree_invariants(inst.n, got["parent"], got["size"], got["pos"], got["order"], got["depth"], got["psize"])
+            if pool == 1:
+                assert got["scan_rounds"] > 0.5 * got["pivots"]   # (blocked list: the dense rewrites are reported here)
+            # element moves: the re-hung subtrees, at most two cut-off runs of a block per pivot and the dense rewrites --
+            # against every position between the old and the new place for the dense array
+            assert got["nodes_moved"] <= got["subtree_nodes"] + 2 * (1 << shift) * got["pivots"] + (inst.n + 1) * got["scan_rounds"]
+
+
+def test_blocked_list_after_every_pivot_and_on_a_warm_start():
+    _, inst = load_synthetic()[0]
+    for cap in range(1, 60):
+        got = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2 | _layout(2, 3), max_pivots=cap, climb_budget=0)
+        ref = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2, max_pivots=cap, climb_budget=0)
+        assert np.array_equal(got["order"], ref["order"]) and np.array_equal(got["psize"], ref["psize"]) and np.array_equal(got["pos"], ref["pos"])
+        check_tree_invariants(inst.n, got["parent"], got["size"], got["pos"], got["order"], got["depth"], got["psize"])
+    cold = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0)
+    warm = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=0 | _layout(3, 0), warm_in_tree=cold["in_tree"],
+                             warm_at_upper=(cold["flow"] == inst.cap) & (inst.cap > 0) & ~cold["in_tree"].astype(bool))
+    assert warm["warm_applied"] and warm["status"] == "optimal" and warm["objective"] == cold["objective"]
+    check_tree_invariants(inst.n, warm["parent"], warm["size"], warm["pos"], warm["order"], warm["depth"], warm["psize"])

@@ -1255,3 +1255,182 @@ def test_adapter_solves_a_benchmark_group_at_once(gpu_engine_module):
         one = Mi355xAdapter.solve(problem)
         assert (got.status, got.objective, got.iterations) == (one.status, one.objective, one.iterations)
         assert got.solver_name == "network_solver_mi355x" and got.solve_time_ms >= 0
+
+
+# ------------------------------------------------------------------ blocked preorder list, candidate cache, resident-rc drop
+@pytest.mark.parametrize("rule", RULES, ids=RULE_IDS)
+def test_blocked_preorder_list_equals_dense_array_on_gpu(gpu_engine_module, rule):
+    """mcf_options.tree_blocks: the tree's preorder in physical blocks with a logical base each (k_update_bpl: O(subtree +
+    block) element moves per basis swap; replaces the per-pivot rebuild basis.py:82-125 / simplex.py:1103-1107).  Same logical
+    preorder as the dense array: pivots, flows, potentials, order, positions, sizes, depths equal the CPU emulation of the
+    DENSE array for every block size, with a generous pool, a small one and none (a dense rewrite into the other arena on
+    every pivot), resident reduced costs or gathers, graph or eager, scan or climb."""
+    e = gpu_engine_module
+    cases = [load_synthetic()[0][1], load_synthetic()[4][1], generators.goto_style(12, 12, seed=4), generators.netgen_style(1024, 8192, seed=5)]
+    for inst in cases:
+        em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
+        for shift, pool in ((2, 0), (2, -1), (3, 5), (6, 0), (6, -1), (8, 3)):
+            for opts in ({}, {"cycle_scan": -1}, {"resident_rc": False}, {"use_graph": False, "climb_depth": -1}, {"full_sweeps": -1}):
+                with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, tree_blocks=shift, tree_pool=pool, **opts) as eng:
+                    eng.solve()
+                    res, tree = eng.result(), eng.tree()
+                assert res.stats["tree_blocks"] == shift and res.stats["pricing_mode"] in (0, 1)
+                assert res.status == em["status"] == "optimal" and res.objective == em["objective"] and res.stats["pivots"] == em["pivots"]
+                assert np.array_equal(res.flow, em["flow"]) and np.array_equal(res.potential, em["potential"])
+                for key in ("order", "pos", "psize", "parent", "depth", "size"):
+                    assert np.array_equal(tree[key], em[key]), key
+                if pool < 0:
+                    assert res.stats["tree_rebuilds"] > 0.5 * res.stats["pivots"]
+                else:
+                    assert res.stats["nodes_moved"] <= res.stats["subtree_nodes"] + 2 * (1 << shift) * res.stats["pivots"] + (inst.n + 1) * res.stats["tree_rebuilds"]
+        check_tree_invariants(inst.n, tree["parent"], tree["size"], tree["pos"], tree["order"], tree["depth"], tree["psize"])
+
+
+def test_candidate_cache_and_reduced_cost_drop(gpu_engine_module):
+    """Candidate-list rule on the grid path: the records of the live list (end points, state, exact reduced cost) are written by
+    the sweep and kept current by every pivot's update pass, so a minor iteration (simplex_pricing.py:419-456) is one read of
+    the list; and a handle may give up its resident reduced costs in mid-solve (mcf_options.rc_drop).  Neither changes a pivot:
+    budgets and resumes, incremental sweeps, gathers, both tree layouts -- always the CPU emulation's pivots, flows, tree."""
+    e = gpu_engine_module
+    for inst in (generators.netgen_style(3000, 24000, seed=11), generators.goto_style(40, 40, seed=12)):
+        em = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2)
+        emf = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2 | 0x100)
+        for layout in (-1, 6):
+            for opts in ({}, {"resident_rc": False}, {"full_sweeps": -1}, {"rc_drop": 1}, {"rc_drop": 1, "full_sweeps": -1}, {"use_graph": False, "rc_drop": 2},
+                         {"forward_first": True}, {"batch_pivots": 7, "rc_drop": 1}):
+                ref = emf if opts.get("forward_first") else em
+                with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2, tree_blocks=layout, fused=False, mid_loop=-1, **opts) as eng:
+                    for budget in (1, 50, 4999):
+                        eng.solve(max_pivots=budget)
+                    eng.solve()
+                    res, tree = eng.result(), eng.tree()
+                    rc, resident = eng.reduced_costs()
+                assert res.status == "optimal" and res.objective == ref["objective"] and res.stats["pivots"] == ref["pivots"], (inst.name, layout, opts)
+                assert np.array_equal(res.flow, ref["flow"]) and np.array_equal(res.potential, ref["potential"]) and np.array_equal(tree["order"], ref["order"])
+                assert np.array_equal(rc, inst.cost + tree["pi"][inst.tail] - tree["pi"][inst.head])
+                if "rc_drop" in opts:   # the switch happened (after the first batches) and the handle says so
+                    assert 0 < res.stats["rc_dropped_at"] < res.stats["pivots"] and res.stats["pricing_mode"] == 0 and not resident
+                else:
+                    assert res.stats["rc_dropped_at"] == 0
+        # a reset brings the resident reduced costs back
+        with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2, rc_drop=1, fused=False, mid_loop=-1) as eng:
+            eng.solve()
+            assert eng.stats()["rc_dropped_at"] > 0
+            eng.reset()
+            eng.solve(max_pivots=100)
+            rc, resident = eng.reduced_costs()
+            assert resident and eng.stats()["rc_dropped_at"] == 0
+            eng.solve()
+            assert eng.result().objective == em["objective"] and eng.stats()["pivots"] == em["pivots"]
+
+
+def _drive_shards(e, inst, rule, G, budget, listing, **opts):
+    """`G` sharded handles on this GPU driven like distributed.PivotLoop drives them over RCCL (the all-gather is a device
+    copy here): per-pivot protocol (one 16-byte candidate per rank) or, `listing`, the candidate-list protocol (one list
+    per rank per minor_cap + 1 pivots).  Stops at `budget` total pivots or at a final status.  Returns the engines (open)."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    engs = [e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, shard=(r, G), device=0, **opts) for r in range(G)]
+    K, minor_cap = engs[0].shard_info() if listing else (1, 0)
+    buf = ctypes.c_void_p()
+    nbytes = 16 * K * G
+    assert hip.hipMalloc(ctypes.byref(buf), 2 * nbytes) == 0 and hip.hipMemset(buf, 0xff, 2 * nbytes) == 0
+    local = [buf.value + 16 * K * r for r in range(G)]
+    gathered = buf.value + nbytes
+    try:
+        for eng in engs:
+            eng.set_max_pivots(budget)
+        for _ in range(100000):
+            for _ in range(8):
+                for r, eng in enumerate(engs):
+                    (eng.enqueue_price_list if listing else eng.enqueue_price)(0, local[r])
+                assert hip.hipMemcpyAsync(gathered, buf.value, nbytes, 3, None) == 0
+                for eng in engs:
+                    if listing:
+                        eng.enqueue_pivots(0, gathered, K * G, minor_cap + 1)
+                    else:
+                        eng.enqueue_pivot(0, gathered, G)
+            assert hip.hipDeviceSynchronize() == 0
+            polls = [eng.poll() for eng in engs]
+            assert len(set(polls)) == 1
+            if polls[0][0] is not None:
+                break
+    finally:
+        hip.hipFree(buf)
+    return engs
+
+
+def _check_shard_state(e, inst, engs, keyed):
+    """Replicas bit-identical; every arc's resident reduced cost exact on the rank that owns it (reduced_costs() merges the
+    rank's own shard with values computed from the potentials); every arc's key code exact on at least its owner."""
+    trees = [eng.tree() for eng in engs]
+    res = [eng.result() for eng in engs]
+    for r, t in zip(res[1:], trees[1:]):
+        assert np.array_equal(r.flow, res[0].flow) and np.array_equal(r.potential, res[0].potential)
+        assert np.array_equal(t["order"], trees[0]["order"]) and np.array_equal(t["parent"], trees[0]["parent"]) and np.array_equal(t["state"], trees[0]["state"])
+    pi = trees[0]["pi"]
+    truth = inst.cost + pi[inst.tail] - pi[inst.head]
+    for eng in engs:
+        rc, resident = eng.reduced_costs()
+        assert resident and np.array_equal(rc, truth)
+    if keyed:
+        bigm = (int(np.abs(inst.cost).max()) + 1) * (inst.n + 2)
+        want = _vkey_code(-(trees[0]["state"].astype(np.int64)) * truth, bigm, 1 << 28)
+        exact_somewhere = np.zeros(inst.m, bool)
+        for eng in engs:
+            keys, present = eng.pricing_keys()
+            assert present
+            exact_somewhere |= keys == want
+        assert exact_somewhere.all()
+    return res[0], trees[0]
+
+
+@pytest.mark.parametrize("protocol", ["per_pivot_dantzig", "candidate_lists"])
+def test_sharded_handles_in_the_configuration_they_really_run_in(gpu_engine_module, protocol):
+    """BASELINE.json configs[3] / configs[4] put sharded handles on arcs >= 4 M, where a Dantzig / candidate-list handle sweeps
+    4-byte key codes, incrementally, and patches only its own shard's reduced costs (mcf_engine.hip: rc_partial, vkey, dirty).
+    That combination with shard_count > 1: three handles on this GPU, key codes + incremental sweeps forced on, (a) netgen_8_14a
+    to optimality and (b) 1 M nodes / 16 M arcs for a budget of 5 000 pivots, on the blocked tree layout.  Replicas bit-identical;
+    reduced costs and key codes exact on every rank's shard; the per-pivot Dantzig protocol pivots exactly like the unsharded
+    engine; the result of (a) is the certified optimum."""
+    e = gpu_engine_module
+    listing = protocol == "candidate_lists"
+    rule = 2 if listing else 0
+    opts = dict(compressed_keys=1, full_sweeps=-1)
+    # (a) to optimality
+    inst = generators.named_instance("netgen_8_14a")
+    engs = _drive_shards(e, inst, rule, 3, 10 ** 9, listing, tree_blocks=6, **opts)
+    try:
+        assert all(eng.stats()["sweep_variant"] & 5 == 5 for eng in engs)      # key codes + incremental really on
+        r0, t0 = _check_shard_state(e, inst, engs, keyed=True)
+    finally:
+        for eng in engs:
+            eng.close()
+    assert r0.status == "optimal"
+    check_optimality(inst, r0.flow, r0.potential)
+    single, ts = _solve(e, inst, rule, fused=False, mid_loop=-1)
+    assert single.objective == r0.objective
+    if not listing:
+        assert single.stats["pivots"] == r0.stats["pivots"] and np.array_equal(single.flow, r0.flow) and np.array_equal(ts["order"], t0["order"])
+    # (b) the million-node shape, a budget of pivots: key codes and incremental sweeps together again, the blocked list by default
+    big = generators.named_instance("netgen_1m_16m")
+    budget = 5000
+    engs = _drive_shards(e, big, rule, 3, budget, listing, **opts)
+    try:
+        st = engs[0].stats()
+        assert st["tree_blocks"] > 0 and st["sweep_variant"] & 5 == 5
+        rb, tb = _check_shard_state(e, big, engs, keyed=True)
+    finally:
+        for eng in engs:
+            eng.close()
+    assert rb.stats["pivots"] >= budget
+    if not listing:   # the unsharded engine, same budget: the same pivots
+        with e.McfEngine(big.n, big.tail, big.head, big.cost, big.cap, big.supply, rule=0) as eng:
+            eng.solve(max_pivots=int(rb.stats["pivots"]))
+            rs, tsb = eng.result(), eng.tree()
+        assert rs.stats["pivots"] == rb.stats["pivots"] and np.array_equal(rs.flow, rb.flow) and np.array_equal(tsb["order"], tb["order"])
