@@ -1061,6 +1061,7 @@ __device__ __forceinline__ void solve_mid_body(const McfView& g, int32_t rule, M
     McfView v = g;
     v.ctx = &S.ctx;
     v.dirty = nullptr;  // mcf_create never combines incremental sweeps with this loop: the marking folds away
+    v.dirty_hdr = nullptr; v.bmeta[0] = nullptr; v.bmeta[1] = nullptr; v.candx = nullptr;   // (nor the blocked list, nor the candidate cache)
     const bool listing = rule == MCF_RULE_CANDIDATE_LIST;
     // the sweep in front of this launch was a no-op if the list was still live (k_price_rc, use_block == 2)
     bool have_fresh = listing && fresh && S.ctx.minor_left <= 0 && S.ctx.status == MCF_RUNNING;
@@ -1333,6 +1334,79 @@ __device__ __forceinline__ void copy_words(void* dst, const void* src, uint32_t 
 #define STAMP(slot) do {} while (0)
 #endif
 
+// ------------------------------------------------------------------ node-parallel cycle search (LDS loop)
+// A tree that fits one workgroup's lanes needs no walk at all: lane x asks whether NODE x is an ancestor of the entering arc's
+// first / second end point -- pos[x] <= pos[u] < pos[x] + size[x], both from LDS -- and, if it is an ancestor of exactly one,
+// files itself at path index depth[u] - depth[x] with its record and position (what the climb would have recorded) and
+// takes part in that side's ratio test; the deepest common ancestor is the join.  Three dependent LDS reads and two wave
+// reductions for the whole cycle, whatever its length, instead of one dependent round per tree level on one or two lanes
+// (the 2-lane climb was 53 % of a pivot on netgen_8_08a).  Same path arrays, same ratio-test winners (first side: lowest
+// index among equal residuals, second side: highest), hence the same pivots.  All threads call it; one barrier inside;
+// lane 0 gets the finished McfCycle.  Requires n_nodes <= THREADS.
+struct SmallCycleAcc {
+    int32_t c1[16], c2[16];   // one-sided ancestors per wave, first / second side
+};
+
+template <int THREADS>
+__device__ __forceinline__ void small_cycle_parallel(const McfView& v, SmallCycleAcc& A, McfCycle* out) {
+    const McfCtx* c = v.ctx;
+    const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
+    const int32_t first = c->pv_first, second = c->pv_second;      // (uniform: LDS broadcast reads)
+    const McfNode r0u = v.node[first], r0w = v.node[second];
+    const int32_t pu = pcur[first], pw = pcur[second];
+    const int32_t x = (int32_t)threadIdx.x, wave = x >> 6;
+    const int32_t N = v.n_nodes, nwaves = (N + 63) >> 6;
+    // scratch in the segment table's LDS (the finish pass only fills it afterwards): residual per path index and side, and
+    // the common ancestors by depth (root .. join occupy depths 0 .. depth[join], one node each)
+    int64_t* const res1 = reinterpret_cast<int64_t*>(v.seg);
+    int64_t* const res2 = res1 + N;
+    int32_t* const by_depth = reinterpret_cast<int32_t*>(res2 + N);
+    bool h1 = false, h2 = false;
+    if (x < N) {
+        const McfNode rec = v.node[x];
+        const int32_t px = pcur[x];
+        const bool au = (uint32_t)(pu - px) < (uint32_t)rec.size, aw = (uint32_t)(pw - px) < (uint32_t)rec.size;
+        if (au && aw) by_depth[rec.depth] = x;
+        else if (au) {
+            const McfArcW a = v.arcw[rec.pred >> 1];
+            const int32_t idx = r0u.depth - rec.depth;
+            v.path1[idx] = x; v.rec1[idx] = rec; v.ppos1[idx] = px;
+            // first side is walked against the flow: an up arc loses flow, a down arc gains
+            res1[idx] = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
+            h1 = true;
+        } else if (aw) {
+            const McfArcW a = v.arcw[rec.pred >> 1];
+            const int32_t idx = r0w.depth - rec.depth;
+            v.path2[idx] = x; v.rec2[idx] = rec; v.ppos2[idx] = px;
+            res2[idx] = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
+            h2 = true;
+        }
+    }
+    if (wave < nwaves) {
+        const int32_t n1w = (int32_t)__popcll(__ballot(h1)), n2w = (int32_t)__popcll(__ballot(h2));
+        if ((x & 63) == 0) { A.c1[wave] = n1w; A.c2[wave] = n2w; }
+    }
+    __syncthreads();
+    if (x == 0) {
+        int32_t n1 = 0, n2 = 0;
+        for (int32_t q = 0; q < nwaves; ++q) { n1 += A.c1[q]; n2 += A.c2[q]; }
+        const int32_t jn = by_depth[r0u.depth - n1];   // the join: the common ancestor right above the first side's path
+        const McfNode rj = v.node[jn];
+        // the ratio tests, exactly the climb's: first side -- strictly smaller wins (lowest index among equals), second side --
+        // smaller or equal wins (highest index among equals)
+        int64_t d1 = MCF_INF, d2 = MCF_INF;
+        int32_t k1 = -1, k2 = -1;
+        for (int32_t i = 0; i < n1; ++i) { const int64_t r = res1[i]; if (r < d1) { d1 = r; k1 = i; } }
+        for (int32_t i = 0; i < n2; ++i) { const int64_t r = res2[i]; if (r <= d2) { d2 = r; k2 = i; } }
+        out->d1 = d1; out->k1 = k1; out->d2 = d2; out->k2 = k2;
+        out->n1 = n1; out->n2 = n2;
+        out->u = jn; out->w = jn; out->ru = rj; out->rw = rj;
+        out->pu = pcur[jn]; out->pw = out->pu; out->su = out->pu; out->sw = out->pu;
+        out->p0u = pu; out->p0w = pw; out->s0u = pu; out->s0w = pw; out->r0u = r0u; out->r0w = r0w;
+        out->small = 0;
+    }
+}
+
 // The whole solve of one LDS-resident instance by one workgroup (k_solve_small: one instance per launch;
 // k_solve_small_batch: one instance per workgroup of the launch)
 __device__ __forceinline__ void solve_small_body(const McfView& g, const SmallLayout& L, int32_t rule,
@@ -1371,6 +1445,7 @@ __device__ __forceinline__ void solve_small_body(const McfView& g, const SmallLa
     v.psz[0] = nullptr;  // always the climb here (see the pivot step); mcf_create keeps no sizes for such a handle
     v.psz[1] = nullptr;
     v.reach = nullptr;
+    v.bmeta[0] = nullptr; v.bmeta[1] = nullptr; v.candx = nullptr; v.dirty = nullptr; v.dirty_hdr = nullptr;   // (folds the blocked list etc. away)
 
     copy_words(smem + L.tail, g.tail, m_pad4);
     copy_words(smem + L.head, g.head, m_pad4);
@@ -1477,24 +1552,34 @@ __device__ __forceinline__ void solve_small_body(const McfView& g, const SmallLa
                 c->arcs_priced += minor ? MCF_NUM_BUCKETS : priced;
             }
         }
-        // With the tree in LDS a climb step costs ~100 cycles of latency: walking beats the workgroup-wide scan and
-        // its barriers (measured 130 K vs 116 K pivots/s on netgen_8_08a), so the LDS loop keeps no position-space
-        // sizes at all.  Lanes 0 and 1 climb one side each (pivot_climb_2lanes), lane 0 does the rest.
-        if (threadIdx.x < 2) {
+        // Cycle search: every lane is a node (small_cycle_parallel) when the tree fits the workgroup; else lanes 0 and 1 climb
+        // one side each (pivot_climb_2lanes).  Lane 0 does the scalar rest.
+        __shared__ int s_go, s_deep;
+        __shared__ McfCycle s_cy;
+        __shared__ SmallCycleAcc s_acc;
+        if (threadIdx.x == 0) {
             MCF_PSTAMP(12);
-            int go = 0;
-            if (threadIdx.x == 0) go = mcf_pivot_begin(v, key, arc, rule) ? 1 : 0;
-            go = __builtin_amdgcn_readfirstlane(go);
+            s_go = mcf_pivot_begin(v, key, arc, rule) ? 1 : 0;
+            if (s_go) { const int32_t du = v.node[c->pv_first].depth, dw = v.node[c->pv_second].depth; s_deep = du > dw ? du : dw; }
             MCF_PSTAMP(13);
-            if (go) {
-                McfCycle cy;
-                const bool ok = pivot_climb_2lanes(v, &cy);
-                MCF_PSTAMP(15);
+        }
+        __syncthreads();
+        if (s_go) {
+            // (end points that hang close to the root -- the first pivots of a cold start -- are climbed: a level or two of
+            //  LDS round trips beat the parallel search's fixed cost: 144 K vs 126 K pivots/s over the first 25 pivots)
+#if defined(MCF_SMALL_CLIMB)   // A/B build: always the two-lane climb
+            if (false) {
+#else
+            if (v.n_nodes <= kSmallThreads && s_deep > 3) {
+#endif
+                small_cycle_parallel<kSmallThreads>(v, s_acc, &s_cy);
+                if (threadIdx.x == 0) { MCF_PSTAMP(15); mcf_pivot_decide(v, mcf_view_paths(v), s_cy); MCF_PSTAMP(16); }
+            } else if (threadIdx.x < 2) {
+                const bool ok = pivot_climb_2lanes(v, &s_cy);
                 if (threadIdx.x == 0) {
-                    if (ok) mcf_pivot_decide(v, mcf_view_paths(v), cy);
+                    if (ok) mcf_pivot_decide(v, mcf_view_paths(v), s_cy);
                     else c->status = MCF_INTERNAL_ERROR;
                 }
-                MCF_PSTAMP(16);
             }
         }
         STAMP(3);
