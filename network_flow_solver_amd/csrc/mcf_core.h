@@ -959,7 +959,7 @@ MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_
 // Four consecutive positions i0 .. i0 + 3 with their subtree sizes: note the ancestors of the node at position pu
 // and / or pw among them (common ancestor -> jpos, one-sided -> hit list).
 MCF_HD void mcf_scan_group(int32_t i0, int32_t s0, const int32_t* sz, int32_t pu, int32_t pw, int32_t pmin, int64_t* jpos_slot,
-                           McfScanAcc* acc, McfHit* hits, int32_t hits_cap, McfHit* spill) {
+                           McfScanAcc* acc, McfHit* hits, int32_t hits_cap, McfHit* spill, bool dense) {
     // Cheap reject of the whole group first: a subtree can hold pu or pw only if it reaches past the lower
     // of the two, and almost every position is a small subtree far to the left of both.
     int32_t zmax = sz[0] > sz[1] ? sz[0] : sz[1];
@@ -971,7 +971,12 @@ MCF_HD void mcf_scan_group(int32_t i0, int32_t s0, const int32_t* sz, int32_t pu
         // i <= p < i + size  <=>  unsigned(p - i) < unsigned(size)   (sizes are positive; 0 marks "no position")
         const bool au = (uint32_t)(pu - i) < (uint32_t)sz[e];
         const bool aw = (uint32_t)(pw - i) < (uint32_t)sz[e];
-        if (au && aw) MCF_ATOMIC_MAX64(jpos_slot, ((int64_t)i << 32) | (uint32_t)(s0 + e));
+        if (au && aw) {
+            // dense array: slot == position, a 32-bit max on the low word does (the high word stays -1 / 0: see the reader);
+            // blocked list: position and slot travel together
+            if (dense) MCF_ATOMIC_MAX32(reinterpret_cast<int32_t*>(jpos_slot), i);
+            else MCF_ATOMIC_MAX64(jpos_slot, ((int64_t)i << 32) | (uint32_t)(s0 + e));
+        }
         else if (au || aw) {
             const int32_t slot = MCF_ATOMIC_ADD32(&acc->nhits, 1);
             const McfHit hrec = ((s0 + e) << 1) | (aw ? 1 : 0);
@@ -1110,11 +1115,11 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
 #pragma unroll
 #endif
                     for (int k = 0; k < MCF_SCAN_GROUPS; ++k)
-                        if (s0k[k] >= 0) mcf_scan_group(i0k[k], s0k[k], szk[k], pu, pw, pmin, &acc->jpos[0], acc, hits, hits_cap, spill);
+                        if (s0k[k] >= 0) mcf_scan_group(i0k[k], s0k[k], szk[k], pu, pw, pmin, &acc->jpos[0], acc, hits, hits_cap, spill, !bpl);
                 }
             }
             MCF_TEAM_BARRIER();
-            jpk = acc->jpos[0];
+            jpk = bpl ? acc->jpos[0] : (int64_t)(int32_t)(acc->jpos[0] & 0xffffffff);   // (dense array: the low word is the position, -1 = none)
             rounds = 2;
             done = true;
         }
@@ -1150,11 +1155,11 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
         for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
             const int32_t slice = lo + k * nlanes * 4;
             if (slice + nlanes * 4 <= 0) continue;
-            mcf_scan_group(slice + lane * 4, slice + lane * 4, sz[k], pu, pw, pmin, &acc->jpos[par], acc, hits, hits_cap, spill);
+            mcf_scan_group(slice + lane * 4, slice + lane * 4, sz[k], pu, pw, pmin, &acc->jpos[par], acc, hits, hits_cap, spill, true);
         }
         MCF_TEAM_BARRIER();
         // the next round's atomics go to the other slot: nobody can overtake a lane still reading this one
-        jpk = acc->jpos[par];
+        jpk = (int64_t)(int32_t)(acc->jpos[par] & 0xffffffff);   // (dense array only gets here)
         par ^= 1;
         ++rounds;
         if (jpk >= 0 || lo <= 0) break;

@@ -970,6 +970,9 @@ def test_baseline_sizes_certified_optimal(gpu_engine_module, name, rule):
     assert res.status == "optimal" and res.stats["artificial_flow"] == 0
     check_optimality(inst, res.flow, res.potential)               # optimal for THIS instance, oracle-free
     assert res.objective == int(np.dot(res.flow, inst.cost))
+    fix = _baseline_objectives().get(name)                         # ... and the pinned value (goto_8_16a: certified on the GPU by two
+    if fix:                                                        # rules and recomputed by the CPU emulation of the integer algorithm)
+        assert inst.sha256() == fix["sha256"] and res.objective == fix["objective"]
     n = inst.n                                                     # vectorised tree invariants
     order, pos, size, parent = tree["order"], tree["pos"], tree["size"], tree["parent"]
     assert np.array_equal(np.sort(order), np.arange(n + 1)) and np.array_equal(order[pos], np.arange(n + 1))
@@ -1126,7 +1129,15 @@ def test_million_node_instance_solved_to_certified_optimality(gpu_engine_module,
     at_upper = ~res.in_tree & (inst.cap > 0) & (res.flow == inst.cap)
     api = nfs.solve_min_cost_flow(prob, warm_start_basis=ArrayBasis(inst.tail, inst.head, res.in_tree, at_upper, res.flow))
     assert api.status == "optimal" and api.objective == float(res.objective)
-    assert api.iterations <= 10_000            # (a few degenerate pivots -- 132 when written -- instead of 3.4 M)
+    # Why not zero pivots: a Basis names REAL arcs only (as the reference's does: artificial arcs never leave the solver,
+    # simplex.py:1744-1765).  The optimal tree keeps `k` artificial arcs basic at zero flow, so the real basic arcs form a forest
+    # of k components; the warm start hangs each component on the root by an artificial arc at its LOWEST node (mcf_host.h:
+    # mcf_apply_basis, like simplex.py:826-873), not where the final tree had it.  That shifts every component's potentials by a
+    # constant, some arcs between components price out again, and a few degenerate pivots per component put it right.
+    k = int(inst.n - int(res.in_tree.sum()))
+    with capsys.disabled():
+        print(f"\n  [netgen_1m_16m] warm start: {api.iterations} pivots for {k} forest components", flush=True)
+    assert api.iterations <= 8 * k + 64        # (132 pivots when first measured -- instead of 3.4 M)
     assert np.array_equal(api.flows.array, res.flow)
 
 
