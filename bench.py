@@ -229,6 +229,26 @@ def measure_single(workload: str, steps: int, warmup: int, rule: int, profile_pa
                     "with rocprofv3's average for the kernel in the same loop); *_event_pairs_in_loop: one event pair around every "
                     "eager launch of the profiled pass of the same K pivots, which includes ~3 us of dispatch latency per launch",
         }
+        # the tree-update kernel of the same pass (k_update / k_update_bpl): SURVEY 8d's algorithmic bytes -- 20 B per node of the
+        # re-hung subtrees + 44 B per arc incident to them (adjacency entry, other end's position, reduced-cost read-modify-write,
+        # state, key code) -- against its duration (event pairs: includes ~3 us of dispatch per launch) and the PMC traffic of
+        # the committed rocprofv3 pass.  A latency chain, not a stream: the fraction of the HBM peak says how far from bandwidth-
+        # bound it is, `bytes_moved_over_needed` how much of what it rewrites is waste (the dense array shifts every position
+        # between the subtree's old and new place; the blocked list moves the subtree and at most two cut-off runs of a block).
+        d_piv = max(p1["pivots"] - p0["pivots"], 1)
+        sub = (p1["subtree_nodes"] - p0["subtree_nodes"]) / d_piv
+        moved = (p1["nodes_moved"] - p0["nodes_moved"]) / d_piv
+        deg = 2.0 * inst.m / max(inst.n, 1)
+        need = 20.0 * sub + (44.0 * deg * sub if mode == 1 else 0.0)
+        uname = ("k_update_bpl" if int(p1.get("tree_blocks", 0)) else "k_update") if mode == 1 else ("k_update_bpl" if int(p1.get("tree_blocks", 0)) else "k_apply")
+        utraffic, usrc = pmc_traffic(workload, uname)
+        out["update_roofline"] = {
+            "kernel": uname, "bound": "hbm", "tree_layout": f"blocked preorder list, blocks of {1 << int(p1['tree_blocks'])} slots" if int(p1.get("tree_blocks", 0)) else "dense preorder array",
+            "subtree_nodes_per_pivot": sub, "positions_rewritten_per_pivot": moved, "bytes_moved_over_needed": (20.0 * moved) / max(20.0 * sub, 1e-9),
+            "algorithmic_bytes_per_launch": need, "ms_per_launch_event_pairs": apply_ms,
+            "achieved": need / max(apply_ms * 1e-3, 1e-12) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": need / max(apply_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBPS, "traffic": utraffic, "traffic_source": usrc,
+            "note": "per launch = per basis swap; 44 B x (2m/n) arcs per re-hung node is the average adjacency, the patched arcs are not counted one by one"}
     eng.close()
     return out
 
@@ -398,7 +418,8 @@ def main():
         line["hbm_point"] = {
             "workload": big["workload"], "value": big["arcs_priced_per_sec"], "unit": "arcs/s",
             "pivots_per_sec": big["pivots_per_sec"], "ms_per_step": big["ms_per_step"], "steps": big["pivots"],
-            "roofline": big.get("roofline"), "kernel_ms": big.get("kernel_ms"),
+            "roofline": big.get("roofline"), "kernel_ms": big.get("kernel_ms"), "update_roofline": big.get("update_roofline"),
+            "note": "a budget shorter than the captured graph runs as eager launches of just the slots it needs (no idle graph slots)",
         }
         try:
             from network_flow_solver_amd import engine
@@ -431,7 +452,7 @@ def main():
         line["hbm_point_beyond_infinity_cache"] = {
             "workload": far["workload"], "value": far["arcs_priced_per_sec"], "unit": "arcs/s",
             "pivots_per_sec": far["pivots_per_sec"], "ms_per_step": far["ms_per_step"], "steps": far["pivots"],
-            "roofline": far.get("roofline"), "kernel_ms": far.get("kernel_ms")}
+            "roofline": far.get("roofline"), "kernel_ms": far.get("kernel_ms"), "update_roofline": far.get("update_roofline")}
         _instances.clear()
     if default_run:
         try:   # secondary points: a failure here must not cost the headline line

@@ -1493,7 +1493,8 @@ MCF_HD void mcf_bpl_prepare(const McfView& v, const McfCtx& c, int32_t lane, int
 // One slot of a block the update has to take apart (host: scalar loop; device: one lane per slot).  `p` = old logical
 // position, `nd` / `z` = node and size in the slot.  Returns what stays in the block as o + z (0: nothing), for the
 // block's new rrel.  `cnt` counts elements copied to the cut-off blocks (diagnostic).
-struct McfBplOut { int32_t keep_reach; int32_t copy_reach[2]; int32_t moved; };
+struct McfBplOut { int32_t keep_reach; int32_t copy_reach[2]; int32_t moved;
+                   int32_t push_blk, push_reach; };   // an element pushed to a block of T2 / of the dense rewrite: the block and o + z there (-1: none)
 MCF_HD void mcf_bpl_slot(const McfView& v, const McfCtx& c, const McfBlkPlan& P, int32_t slot, int32_t p, int32_t nd, int32_t z,
                          McfBplOut* out) {
     const int32_t bs = v.blk_shift, bmask = (1 << bs) - 1;
@@ -1504,7 +1505,7 @@ MCF_HD void mcf_bpl_slot(const McfView& v, const McfCtx& c, const McfBlkPlan& P,
     int32_t* const psz_new = c.rebuild ? (c.arena ? v.psz[0] : v.psz[1]) : psz_old;
     const int32_t arena_new = (c.rebuild ? (c.arena ^ 1) : c.arena) ? MCF_LOC_ARENA : 0;
     McfBlkMeta* const bn = c.cur ? v.bmeta[0] : v.bmeta[1];
-    out->keep_reach = 0; out->copy_reach[0] = 0; out->copy_reach[1] = 0; out->moved = 0;
+    out->keep_reach = 0; out->copy_reach[0] = 0; out->copy_reach[1] = 0; out->moved = 0; out->push_blk = -1; out->push_reach = 0;
     const bool in_t2 = p >= a0 && p < a0 + S;
     int32_t dslot = -1;
     if (in_t2) {
@@ -1513,10 +1514,10 @@ MCF_HD void mcf_bpl_slot(const McfView& v, const McfCtx& c, const McfBlkPlan& P,
         v.pi[nd] += c.sigma;
         if (dd) v.node[nd].depth += dd;
         dslot = c.rebuild ? j : ((c.alloc_lo + MCF_BLK_COPIES) << bs) + (j - c.t2_new);
-        MCF_ATOMIC_MAX32(&bn[dslot >> bs].rrel, (dslot & bmask) + z);
+        out->push_blk = dslot >> bs; out->push_reach = (dslot & bmask) + z;   // (the caller raises that block's rrel: wave-wide on the device)
     } else if (c.rebuild) {
         dslot = p + mcf_bpl_shift(c, p);
-        MCF_ATOMIC_MAX32(&bn[dslot >> bs].rrel, (dslot & bmask) + z);
+        out->push_blk = dslot >> bs; out->push_reach = (dslot & bmask) + z;
     } else if (p >= P.r0lo && p < P.r0hi) {
         out->keep_reach = (slot & bmask) + z;
         return;
@@ -1531,7 +1532,7 @@ MCF_HD void mcf_bpl_slot(const McfView& v, const McfCtx& c, const McfBlkPlan& P,
     psz_new[dslot] = z;
     psz_old[slot] = 0;                       // the old slot is empty from now on (size 0: the scan skips it)
     v.posbuf[0][nd] = dslot | arena_new;
-    (void)tok_old;
+    (void)tok_old; (void)bn;
 }
 
 // Is `node` (a neighbour of a T2 node) inside T2?  Asked by the reduced-cost patch while other lanes may be moving it:
@@ -1571,7 +1572,10 @@ MCF_HD void mcf_bpl_update_seq(const McfView& v, const McfCtx& c) {
             const int32_t slot = (b << bs) + o;
             McfBplOut r;
             if (!c.rebuild && !P.touched) { r.keep_reach = o + psz[slot]; r.copy_reach[0] = r.copy_reach[1] = 0; r.moved = 0; }   // re-index only
-            else mcf_bpl_slot(v, c, P, slot, m.base + o, tok[slot], psz[slot], &r);
+            else {
+                mcf_bpl_slot(v, c, P, slot, m.base + o, tok[slot], psz[slot], &r);
+                if (r.push_blk >= 0 && r.push_reach > bn[r.push_blk].rrel) bn[r.push_blk].rrel = r.push_reach;
+            }
             if (r.keep_reach > keep) keep = r.keep_reach;
             if (r.copy_reach[0] > cr[0]) cr[0] = r.copy_reach[0];
             if (r.copy_reach[1] > cr[1]) cr[1] = r.copy_reach[1];

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(kRcupdThreads) void k_update(McfView g, int apply_b
 constexpr int kBplThreads = 1024;
 constexpr int kBplTouchedCap = 2048;   // blocks one workgroup can list (mcf_create sizes the grid so that a workgroup owns no more)
 constexpr int kBplT2Cap = 8192;        // T2 nodes one workgroup can list (more: patched on the spot by the lane that moved them)
-constexpr int kBplSegLds = 64;         // segment-table entries the direct workgroup stages in LDS
+constexpr int kBplSegLds = 1024;       // segment-table entries a workgroup stages in LDS (one per thread) before it moves T2 elements
 constexpr int kBplListMember = 32;     // a T2 this small that sits in one block: membership by scanning the LDS list
 
 // `whole` != null: the listed nodes are ALL of T2 (n of them): the other end is inside iff it is in the list
@@ -659,6 +659,7 @@ __device__ __forceinline__ void bpl_block(const McfView& v, const McfView& segv,
     int32_t keep = 0, cr0 = 0, cr1 = 0;
     for (int32_t o0 = beg & ~63; o0 < end; o0 += 64) {
         const int32_t o = o0 + lane, q = o0 >> 6;
+        int32_t pblk = -1, pval = 0;   // this lane's pushed element: destination block and o + z there
         if (o >= beg && o < end) {
             const int32_t slot = (b << bs) + o;
             int32_t z, nd;
@@ -669,6 +670,7 @@ __device__ __forceinline__ void bpl_block(const McfView& v, const McfView& segv,
                 const int32_t p = m.base + o;
                 McfBplOut r;
                 mcf_bpl_slot(segv, c, P, slot, p, nd, z, &r);
+                pblk = r.push_blk; pval = r.push_reach;
                 keep = keep > r.keep_reach ? keep : r.keep_reach;
                 cr0 = cr0 > r.copy_reach[0] ? cr0 : r.copy_reach[0];
                 cr1 = cr1 > r.copy_reach[1] ? cr1 : r.copy_reach[1];
@@ -678,6 +680,15 @@ __device__ __forceinline__ void bpl_block(const McfView& v, const McfView& segv,
                     else bpl_patch_node<MARK>(v, c, nd, 0, 1);   // list full: this lane patches the node's arcs itself
                 }
             }
+        }
+        // the pushed elements raise the rrel of the blocks they land in: one atomic per destination block and chunk (consecutive
+        // old positions mostly land in one or two blocks), not one per element -- thousands of them on a few dozen words otherwise
+        for (uint64_t todo = __ballot(pblk >= 0); todo;) {
+            const int32_t b0 = __builtin_amdgcn_readlane(pblk, (int)__ffsll((unsigned long long)todo) - 1);
+            const bool mine = pblk == b0;
+            const int32_t mx = wave_max32(mine ? pval : 0);
+            if (lane == 0) atomicMax(&bn[b0].rrel, mx);
+            todo &= ~__ballot(mine);
         }
     }
     if (c.rebuild) return;   // (the old arena is left empty; its records die with the flip)
@@ -708,7 +719,9 @@ __global__ __launch_bounds__(kBplThreads) void k_update_bpl(McfView g, int G) {
     __shared__ McfSeg s_seg[kBplSegLds];
     const bool direct = (int32_t)blockIdx.x == G;
     if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&cs)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
-    if (direct && threadIdx.x >= 128 && threadIdx.x < 128 + kBplSegLds) s_seg[threadIdx.x - 128] = g.seg[threadIdx.x - 128];   // (scratch of 2 n + 2 entries: always readable)
+    // the direct workgroup will search the segment table for sure: it fetches it together with the control block (the scratch
+    // holds 2 n + 2 entries: reading the first 64 is always in bounds; longer tables are staged below, once nseg is known)
+    if (direct && threadIdx.x >= 128 && threadIdx.x < 128 + 64) s_seg[threadIdx.x - 128] = g.seg[threadIdx.x - 128];
     if (threadIdx.x == 0) { s_nt = 0; s_nn = 0; }
     __syncthreads();
     const McfCtx& c = cs;
@@ -721,6 +734,10 @@ __global__ __launch_bounds__(kBplThreads) void k_update_bpl(McfView g, int G) {
     if (direct) {
         if (c.rebuild) return;
         McfView segv = v;
+        if (c.nseg > 64 && c.nseg <= kBplSegLds) {   // (uniform) a longer table: the rest of it, one entry per thread
+            if ((int32_t)threadIdx.x >= 64 && (int32_t)threadIdx.x < c.nseg) s_seg[threadIdx.x] = g.seg[threadIdx.x];
+            __syncthreads();
+        }
         if (c.nseg <= kBplSegLds) segv.seg = s_seg;
         if (RC && c.pv_t2n == 1) {
             // T2 is one node and the pivot kernel sent its adjacency range along: the patch needs no look-up at all
@@ -776,7 +793,15 @@ __global__ __launch_bounds__(kBplThreads) void k_update_bpl(McfView g, int G) {
     // ---- B
     const int32_t nt = s_nt < kBplTouchedCap ? s_nt : kBplTouchedCap;
     if (nt == 0) return;   // (uniform: the usual case for every workgroup but a few)
-    for (int32_t t = wave; t < nt; t += kBplThreads / 64) bpl_block<MARK, RC>(v, v, c, g.ctx, s_tb[t], lane, s_t2, &s_nn);
+    // the elements of T2 look their new position up in the segment table (a binary search: log2(nseg) dependent loads each):
+    // from LDS when the table fits (a stem of <= 511 nodes), staged by the whole workgroup in one round trip
+    McfView segv = v;
+    if (c.nseg <= kBplSegLds) {
+        if ((int32_t)threadIdx.x < c.nseg) s_seg[threadIdx.x] = g.seg[threadIdx.x];
+        __syncthreads();
+        segv.seg = s_seg;
+    }
+    for (int32_t t = wave; t < nt; t += kBplThreads / 64) bpl_block<MARK, RC>(v, segv, c, g.ctx, s_tb[t], lane, s_t2, &s_nn);
     if (!RC) return;
     __syncthreads();
     // ---- C
