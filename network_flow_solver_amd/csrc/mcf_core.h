@@ -895,7 +895,9 @@ MCF_HD bool mcf_pivot_climb(const McfView& v, const McfPaths& pb, McfCycle* cy, 
 //   ratio:   every lane keeps the best residual of the elements it met (side 1: lowest index among
 //            ties, side 2: highest -- the climb's `<` / `<=`); hit t is handled by lane t, so only the
 //            first ceil(nhits / 64) waves hold anything: they reduce by shuffles, lane 0 combines their results.
+#ifndef MCF_SCAN_GROUPS
 #define MCF_SCAN_GROUPS 4  // 16-byte loads in flight per lane and round
+#endif
 struct McfScanBest { int64_t b1r, b2r; int32_t b1i, b2i; };
 
 MCF_HD void mcf_scan_best_merge(McfScanBest* a, int64_t r1, int32_t i1, int64_t r2, int32_t i2) {

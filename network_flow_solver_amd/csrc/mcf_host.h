@@ -392,12 +392,13 @@ struct McfBplImage {
     std::vector<int32_t> ext[2];                // [cap]
 };
 
-// Block size by tree size (the pivot kernel reads one {base, rrel} record per block handed out: keep that pass at a few
-// thousand records) and pool size; `shift` / `pool` > 0 override (tests use tiny blocks and pools; pool < 0 = no spare
+// Block size by tree size and pool size.  The pivot kernel reads one {base, rrel} record per block handed out (small blocks: a
+// long pass) and, per ancestor of the entering arc's end points, one whole block of sizes (large blocks: a lot of bytes through
+// one CU): measured at 1 M nodes, whole solve, 64 / 128 / 256 slots: 108.8 / 105.8 / 107.6 s -- up to 8 192 dense blocks; `shift` / `pool` > 0 override (tests use tiny blocks and pools; pool < 0 = no spare
 // blocks at all, i.e. a dense rewrite on every pivot).
 inline void mcf_bpl_geometry(int32_t n_nodes, int32_t shift, int32_t pool, int32_t* shift_out, int32_t* cap_out, int32_t* dense_out) {
     int32_t sh = shift;
-    if (sh <= 0) { sh = 6; while (sh < 10 && (n_nodes >> sh) > 4096) ++sh; }
+    if (sh <= 0) { sh = 6; while (sh < 10 && (n_nodes >> sh) > 8192) ++sh; }
     if (sh < 2) sh = 2;
     if (sh > 10) sh = 10;
     const int32_t dense = (int32_t)(((int64_t)n_nodes + (1 << sh) - 1) >> sh);
