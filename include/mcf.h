@@ -137,7 +137,13 @@ typedef struct mcf_options {
                                 patch of the incident arcs' reduced costs costs more per pivot than the dearer sweeps.  0 = auto
                                 (candidate list from 100 000 nodes on: 384; else never), -1 = never, k > 0 = that threshold (candidate
                                 list and Devex; the Dantzig rule sweeps every arc on every pivot and never drops).  Same pivots. */
-    int32_t pad0;
+    int32_t pivot_run;       /* candidate-list handles on the blocked list: a list period is one sweep + this many pairs of (k_pivot_run:
+                                pivots back to back in ONE workgroup, each followed by its update in place, until an update is too large
+                                for one workgroup or the list is used up; k_update_bpl: that update on the grid).  0 = off (measured
+                                slower than the pair shape at 1M/16M: 30.9-35.7 K against 41.1 K pivots/s; the
+                                environment variable MCF_PIVOT_RUN=k turns it on for an A/B), k > 0 = k pairs (the handle goes back
+                                to one k_pivot per slot once its run launches end after fewer than three pivots on average).
+                                Same pivots in the same order. */
 } mcf_options;
 
 typedef struct mcf_stats {
@@ -176,6 +182,8 @@ typedef struct mcf_stats {
     int64_t tree_blocks;      /* log2 of the block size of the blocked preorder list, 0 = dense preorder array */
     int64_t tree_rebuilds;    /* blocked list: pivots whose update rewrote the whole list densely (the block pool had run out) */
     int64_t rc_dropped_at;    /* pivot count at which the handle gave up its resident reduced costs (mcf_options.rc_drop), 0 = it has not */
+    int64_t run_pairs;        /* (k_pivot_run, k_update_bpl) pairs per list period right now (mcf_options.pivot_run), 0 = one k_pivot per slot */
+    int64_t run_left_at;      /* pivot count at which the handle went back to one k_pivot per slot, 0 = it has not */
 } mcf_stats;
 
 /* Called from mcf_solve every cb_interval pivots (simplex.py:1143-1154).

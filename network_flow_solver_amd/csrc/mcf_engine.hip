@@ -633,7 +633,7 @@ __device__ __forceinline__ void bpl_patch_node(const McfView& v, const McfCtx& c
 // One wave takes block b apart (phase B).  `segv`: the view with the segment table wherever it is cheapest to search.
 template <bool MARK, bool RC>
 __device__ __forceinline__ void bpl_block(const McfView& v, const McfView& segv, const McfCtx& c, McfCtx* gctx, int32_t b, int32_t lane,
-                                          int32_t* s_t2, int32_t* s_nn) {
+                                          int32_t* s_t2, int32_t* s_nn, bool list = true, int32_t t2_cap = kBplT2Cap) {
     const int32_t bs = v.blk_shift;
     const McfBlkMeta* __restrict__ bm = c.cur ? v.bmeta[1] : v.bmeta[0];
     McfBlkMeta* __restrict__ bn = c.cur ? v.bmeta[0] : v.bmeta[1];
@@ -674,9 +674,9 @@ __device__ __forceinline__ void bpl_block(const McfView& v, const McfView& segv,
                 keep = keep > r.keep_reach ? keep : r.keep_reach;
                 cr0 = cr0 > r.copy_reach[0] ? cr0 : r.copy_reach[0];
                 cr1 = cr1 > r.copy_reach[1] ? cr1 : r.copy_reach[1];
-                if (RC && p >= c.t2_old && p < c.t2_old + c.t2_size) {
+                if (RC && list && p >= c.t2_old && p < c.t2_old + c.t2_size) {
                     const int32_t li = atomicAdd(s_nn, 1);
-                    if (li < kBplT2Cap) s_t2[li] = nd;
+                    if (li < t2_cap) s_t2[li] = nd;
                     else bpl_patch_node<MARK>(v, c, nd, 0, 1);   // list full: this lane patches the node's arcs itself
                 }
             }
@@ -994,6 +994,169 @@ __global__ __launch_bounds__(kPivotThreads) void k_pivot(McfView g, const McfCan
     __syncthreads();
     MCF_PSTAMP(10);
     if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i]; g_pivot_stamps[23] += 1; }
+#endif
+}
+
+// ------------------------------------------------------------------ k_pivot_run: pivots of a candidate list back to back
+// Blocked list + candidate cache + candidate-list rule.  Almost every pivot of a large sparse instance re-hangs a handful of
+// nodes: its whole update is a few block records, a few dozen reduced costs and the list's records -- work for ONE workgroup.
+// This kernel therefore keeps going: pivot, update in place (bpl_update_inline), next minor iteration, ... until the list is
+// used up, a pivot's update is too large for one workgroup (the descriptor is then left for the k_update_bpl launch that
+// follows, exactly as k_pivot leaves it) or `max_steps` is reached.  What it saves per pivot: two launch boundaries, the
+// control block's trip through memory and back, the staging of the list.  The pivots are the same ones in the same order:
+// every step is k_pivot's step and k_update_bpl's passes, run by one workgroup instead of a grid.
+constexpr int kRunTouchedCap = 2048, kRunT2Cap = 2048, kRunSegCap = 256;
+constexpr int kRunMaxSubtree = 64;     // larger re-hung subtrees go to the grid
+
+struct RunShared {
+    int32_t nt, nn;
+    int32_t tb[kRunTouchedCap];
+    int32_t t2[kRunT2Cap];
+    McfSeg seg[kRunSegCap];
+};
+
+// k_update_bpl's passes by the calling workgroup alone (NT threads; not for ctx.rebuild).  `c` is the control block in LDS.
+template <bool MARK, bool RC, int NT>
+__device__ __forceinline__ void bpl_update_inline(const McfView& v, McfCtx& c, RunShared& R) {
+    const int32_t tid = (int32_t)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) { R.nt = 0; R.nn = 0; }
+    if (tid < c.nseg && tid < kRunSegCap) R.seg[tid] = v.seg[tid];
+    __syncthreads();
+    McfView segv = v;
+    if (c.nseg <= kRunSegCap) segv.seg = R.seg;
+    const int32_t known0 = c.t2_blk, known1 = c.ins_blk;
+    const bool preview = RC && c.pv_t2n == 1;
+    const McfBlkMeta* bm = c.cur ? v.bmeta[1] : v.bmeta[0];
+    McfBlkMeta* bn = c.cur ? v.bmeta[0] : v.bmeta[1];
+    const int32_t* xa = c.arena ? v.bext[1] : v.bext[0];
+    if (wave < 2) {
+        const int32_t kb = wave == 0 ? known0 : ((known1 >= 0 && known1 != known0) ? known1 : -1);
+        if (kb >= 0) bpl_block<MARK, RC>(v, segv, c, &c, kb, lane, R.t2, &R.nn, !preview, kRunT2Cap);
+    } else if (preview && wave >= NT / 128) {
+        // the one node of T2: its adjacency range came with the pivot (second half of the workgroup)
+        const int64_t sigma = c.sigma;
+        const int32_t t0 = tid - NT / 2, nt = NT / 2;
+        for (int64_t p = c.pv_adj[0] + t0; p < c.pv_adj[1]; p += nt) {
+            const int64_t ent = v.adj[p];
+            const int32_t e = (int32_t)((uint32_t)ent >> 1);
+            const int64_t r = v.rcache[e] + ((ent & 1) ? sigma : -sigma);
+            v.rcache[e] = r;
+            if (v.vkey) v.vkey[e] = mcf_vkey(-(int64_t)v.state[e] * r, v.vk_bigm, v.vk_half);
+            if (MARK) mcf_mark_dirty(v, e);
+        }
+    } else {
+        // phase A: the other blocks, one lane per block (the lanes of waves 2 .. that are not patching)
+        const int32_t a_lanes = (preview ? NT / 2 : NT) - 128, a0 = tid - 128;
+        const int32_t nold = c.alloc_prev;
+        // eight blocks per lane and trip, all their loads in flight together (one block per trip was a chain of dependent
+        // round trips: 20 K blocks over 400-900 lanes = 25-50 of them per pivot)
+        constexpr int KA = 8;
+        for (int32_t b0 = a0; b0 < nold; b0 += a_lanes * KA) {
+            McfBlkMeta mm[KA];
+            int32_t xx[KA];
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                const int32_t b = b0 + k * a_lanes;
+                const int32_t bc = b < nold ? b : a0;   // clamp: keep the loads unconditional
+                mm[k] = bm[bc];
+                xx[k] = xa[bc];
+            }
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                const int32_t b = b0 + k * a_lanes;
+                if (b >= nold || b == known0 || b == known1) continue;
+                const McfBlkMeta m = mm[k];
+                const int32_t x = xx[k], beg = mcf_ext_beg(x), end = mcf_ext_end(x);
+                if (m.base == MCF_BLK_FREE || end <= beg) { bn[b] = McfBlkMeta{MCF_BLK_FREE, 0}; continue; }
+                bool apart = (x & MCF_EXT_FLAG) != 0;
+                if (!apart) {
+                    const McfBlkPlan P = mcf_bpl_plan(c, m.base, m.base + beg, m.base + end);
+                    if (P.touched) apart = true; else bn[b] = McfBlkMeta{P.nbase, m.rrel};
+                }
+                if (apart) {
+                    const int32_t slot = atomicAdd(&R.nt, 1);
+                    if (slot < kRunTouchedCap) R.tb[slot] = b;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int32_t nt = R.nt < kRunTouchedCap ? R.nt : kRunTouchedCap;   // (at most the re-index flags of the cycle + T2's other blocks)
+    for (int32_t t = wave; t < nt; t += NT / 64) bpl_block<MARK, RC>(v, segv, c, &c, R.tb[t], lane, R.t2, &R.nn, !preview, kRunT2Cap);
+    __syncthreads();
+    if (RC && !preview) {
+        const int32_t nn = R.nn < kRunT2Cap ? R.nn : kRunT2Cap;
+        const bool whole = nn == c.t2_size && nn <= kBplListMember;
+        for (int32_t t = tid >> 4; t < nn; t += NT / 16) bpl_patch_node<MARK>(v, c, R.t2[t], tid & 15, 16, whole ? R.t2 : nullptr, nn);
+    }
+    candx_pass(v, c, tid, NT);
+}
+
+template <bool MARK, bool RC>
+__global__ __launch_bounds__(kPivotThreads) void k_pivot_run(McfView g, int ncand, int have_sweep, int max_steps) {
+    __shared__ PivotShared S;
+    __shared__ RunShared R;
+#ifdef MCF_STAMPS
+    if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) mcf_stamp_acc[i] = 0; mcf_stamp_last = __builtin_amdgcn_s_memtime(); }
+#endif
+    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(&S.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(g.ctx)[threadIdx.x];
+    if (MARK && g.dirty && threadIdx.x >= 512 && threadIdx.x < 512 + 17) S.dirty_hdr[threadIdx.x - 512] = reinterpret_cast<const int32_t*>(g.dirty)[threadIdx.x - 512];
+    __syncthreads();
+    McfView v = g;
+    v.ctx = &S.ctx;
+    if (!MARK) v.dirty = nullptr;
+    else v.dirty_hdr = reinterpret_cast<const McfDirty*>(S.dirty_hdr);
+    if (threadIdx.x == 0) S.ctx.apply = 0;   // (a descriptor left by an earlier launch has been carried out by the update launch in between)
+    const int32_t rule = MCF_RULE_CANDIDATE_LIST;
+    int steps = 0;
+    for (;; ++steps) {
+        // uniform control values are read BEFORE a barrier (lane 0 rewrites them later in the iteration)
+        const int32_t status_now = S.ctx.status, minor_left = S.ctx.minor_left;
+        const bool sweep_now = steps == 0 && have_sweep;
+        __syncthreads();
+        if (steps >= max_steps || status_now != MCF_RUNNING || (!sweep_now && minor_left <= 0)) break;
+        MCF_PSTAMP(0);
+        // the list's records (kept current by the update passes; after this workgroup's own in-place updates they come from its
+        // L2): state and exact reduced cost give the key a sweep would find now
+        McfCandX x0, x1;
+        x0.arc = -1; x1.arc = -1; x0.rc = 0; x1.rc = 0; x0.state = 0; x1.state = 0; x0.tail = x0.head = x1.tail = x1.head = 0;
+        if ((int)threadIdx.x < ncand) x0 = g.candx[threadIdx.x];
+        if ((int)threadIdx.x + kPivotThreads < ncand) x1 = g.candx[threadIdx.x + kPivotThreads];
+        if (threadIdx.x == 0) S.win_idx = -1;
+        int64_t key = 0, arc = -1;
+        const int64_t v0 = -(int64_t)x0.state * x0.rc, v1 = -(int64_t)x1.state * x1.rc;
+        const int64_t k0 = (x0.arc >= 0 && v0 > 0) ? mcf_dantzig_key(v, x0.arc & 0xffffffff, v0, x0.state) : 0;
+        const int64_t k1 = (x1.arc >= 0 && v1 > 0) ? mcf_dantzig_key(v, x1.arc & 0xffffffff, v1, x1.state) : 0;
+        if (mcf_cand_better(k0, x0.arc, key, arc)) { key = k0; arc = x0.arc; }
+        if (mcf_cand_better(k1, x1.arc, key, arc)) { key = k1; arc = x1.arc; }
+        const int64_t priced = minor_left > 0 ? ncand : v.m;
+        if (ncand <= 64) { if (threadIdx.x < 64) wave_argmax(key, arc); }
+        else block_argmax<kPivotThreads>(key, arc);
+        if (threadIdx.x == 0) S.win_arc = key > 0 ? arc : -1;
+        __syncthreads();
+        const int64_t wa = S.win_arc;
+        if (wa >= 0 && x0.arc == wa) { S.winx = x0; S.win_idx = (int32_t)threadIdx.x; }
+        else if (wa >= 0 && x1.arc == wa) { S.winx = x1; S.win_idx = (int32_t)threadIdx.x + kPivotThreads; }
+        __syncthreads();
+        MCF_PSTAMP(1);
+        pivot_core(v, S, key, arc, rule, priced, true);
+        __syncthreads();
+        if (!S.ctx.apply) continue;   // a bound flip (or nothing to pivot on): no tree change
+        // the update: here when it is small, else by the grid launch that follows
+        if (S.ctx.rebuild || S.ctx.t2_size > kRunMaxSubtree) break;
+        bpl_update_inline<MARK, RC, kPivotThreads>(v, S.ctx, R);
+        __syncthreads();
+        if (threadIdx.x == 0) S.ctx.apply = 0;   // (pending_flip stays: the next begin switches to the copies just written)
+        // what this workgroup has just stored must not be served from a stale line of the scalar cache (uniform loads of the
+        // block records); the vector L1 is write-through and shared by the whole workgroup
+        __builtin_amdgcn_s_dcache_inv();
+    }
+    __syncthreads();
+    if (threadIdx.x < kCtxWords) reinterpret_cast<int32_t*>(g.ctx)[threadIdx.x] = reinterpret_cast<const int32_t*>(&S.ctx)[threadIdx.x];
+#ifdef MCF_STAMPS
+    __syncthreads();
+    MCF_PSTAMP(10);
+    if (threadIdx.x == 0) { for (int i = 0; i < 24; ++i) g_pivot_stamps[i] += mcf_stamp_acc[i]; g_pivot_stamps[23] += steps; }
 #endif
 }
 
@@ -1771,6 +1934,11 @@ struct mcf_handle {
     bool solved_once = false;
     // resident reduced costs -> pricing from the potentials, once the re-hung subtrees have grown so large that patching
     // the reduced costs of their incident arcs costs more per pivot than the dearer sweeps (mcf_solve decides between batches)
+    // candidate-list handles on the blocked list: pivots back to back in one workgroup while the updates are small (k_pivot_run)
+    int run_pairs = 0;         // > 0: a list period is one sweep + this many (k_pivot_run, k_update_bpl) pairs; 0: one k_pivot per slot
+    int run_low = 0;           // consecutive batches that made poor use of their run launches
+    int run_pairs_cfg = 0;     // what mcf_create decided (a reset goes back to it)
+    int64_t run_seen = 0;      // pivot count at the last look
     bool rc_able = false;      // the handle was created with resident reduced costs
     bool rc_dropped = false;   // ... and has stopped keeping them (until the next reset / warm start)
     int64_t rc_drop_subtree = 0;   // average |T2| over a batch from which on they are dropped (0: never)
@@ -1885,6 +2053,13 @@ int upload_image(mcf_handle* h) {
         h->graph_batch = 0;
     }
     h->sw_pivots = 0; h->sw_subtree = 0;
+    if (h->run_pairs != h->run_pairs_cfg) {   // (a fresh start gets the run shape back)
+        h->run_pairs = h->run_pairs_cfg;
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+        h->graph_batch = 0;
+    }
+    h->run_low = 0; h->run_seen = 0;
     HIP_TRY(h, h2d(h, h->d_tail, im.tail.data(), im.m_pad * 4));
     HIP_TRY(h, h2d(h, h->d_head, im.head.data(), im.m_pad * 4));
     HIP_TRY(h, h2d(h, h->d_cost, im.cost.data(), im.m_pad * 4));
@@ -2058,6 +2233,25 @@ void launch_apply(mcf_handle* h, hipStream_t s) {
     }
 }
 
+// One list period in "run" shape: the sweep (a no-op while the list is live), then `run_pairs` pairs of (pivots back to back
+// until an update is too large for one workgroup or the list is used up, that update on the grid).
+void launch_run_period(mcf_handle* h, hipStream_t s) {
+    const int32_t rule = h->opt.rule;
+    const int steps = mcf_minor_cap(h->price_blocks) + 1;
+    launch_price(h, s, h->view, rule, 1);
+    for (int i = 0; i < h->run_pairs; ++i) {
+        const dim3 one(1), block(kPivotThreads);
+        const int sweep = i == 0 ? 1 : 0;
+        if (h->rcached) {
+            if (h->view.dirty) hipLaunchKernelGGL((k_pivot_run<true, true>), one, block, 0, s, h->view, h->price_blocks, sweep, steps);
+            else hipLaunchKernelGGL((k_pivot_run<false, true>), one, block, 0, s, h->view, h->price_blocks, sweep, steps);
+        } else {
+            hipLaunchKernelGGL((k_pivot_run<false, false>), one, block, 0, s, h->view, h->price_blocks, sweep, steps);
+        }
+        launch_apply(h, s);
+    }
+}
+
 // One pivot slot.  Candidate-list rule: only every (minor_cap + 1)-th slot carries a pricing launch;
 // the slots in between go straight to k_pivot, which re-prices the list (a pricing launch there
 // would be a no-op anyway -- this just saves its launch boundary).
@@ -2093,7 +2287,10 @@ int build_graph(mcf_handle* h, int batch) {
         }
     }
     HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    if (!h->overlap) {
+    if (h->run_pairs > 0) {
+        const int period = mcf_minor_cap(h->price_blocks) + 1;
+        for (int i = 0; i < batch / period; ++i) launch_run_period(h, h->stream);
+    } else if (!h->overlap) {
         for (int i = 0; i < batch; ++i) launch_pivot_triplet(h, h->stream, i);
     } else {
         // main:  [price 0] pivot t -> permutation t ------------------------> pivot t+1 ...
@@ -2498,6 +2695,14 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
         if ((e = hipMemset(h->d_candx, 0xff, kMaxPriceBlocks * sizeof(McfCandX))) != hipSuccess) return fail("hipMemset candidate records", e);
         v.candx = h->d_candx; v.ncandx = h->price_blocks;
     }
+    // pivots back to back (k_pivot_run): candidate-list handles on the blocked list that keep the candidate cache
+    h->run_pairs_cfg = 0;
+    // Opt-in: measured at 1M/16M (first 300 K pivots, same box) 30.9-35.7 K pivots/s in the run shape against 41.1 K in the
+    // pivot+update pair shape -- one workgroup's phase A over 8-20 K blocks costs more than the launches it saves.
+    const char* run_env = std::getenv("MCF_PIVOT_RUN");
+    const int want_run = opt.pivot_run > 0 ? opt.pivot_run : (run_env ? std::atoi(run_env) : 0);
+    if (h->bpl && v.candx && want_run > 0 && opt.use_graph && !std::getenv("MCF_NO_RUN")) h->run_pairs_cfg = want_run;
+    h->run_pairs = h->run_pairs_cfg;
     h->rc_able = h->rcached;
     {
         // auto: candidate lists (one sweep per ~33 pivots) on large instances (from 100 000 nodes: measured at 1 M / 16 M) from an
@@ -2643,6 +2848,25 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
             }
             h->stats.batches += 1;
             if (h->h_ctx->status != MCF_RUNNING) break;
+            // Run shape: still worth it?  A run launch that ends after a pivot or two (its update was too large for one
+            // workgroup) is a k_pivot with extra baggage, and a period then needs more launches than the shape holds.  Three
+            // batches in a row with fewer than three pivots per run launch: back to one k_pivot per slot, for good.
+            if (h->run_pairs > 0 && graph) {
+                const int period = mcf_minor_cap(h->price_blocks) + 1;
+                const int64_t made = h->h_ctx->pivots - h->run_seen;
+                h->run_seen = h->h_ctx->pivots;
+                const int64_t launches = (int64_t)(batch / period) * h->run_pairs;
+                h->run_low = made < 3 * launches ? h->run_low + 1 : 0;
+                if (h->run_low >= 3) {
+                    h->run_pairs = 0;
+                    h->stats.run_left_at = h->h_ctx->pivots;
+                    (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr;
+                    (void)hipGraphDestroy(h->graph); h->graph = nullptr;
+                    h->graph_batch = 0;
+                    rc = build_graph(h, batch);
+                    if (rc) return rc;
+                }
+            }
             // Drop the resident reduced costs?  Their patch walks the adjacency of every node of the re-hung subtree: a few
             // arcs early in a solve, hundreds of thousands of random read-modify-writes per pivot once subtrees of thousands
             // of nodes move (1 M / 16 M, last third of the solve: 20+ us of a pivot).  Pricing from the potentials costs a
@@ -2884,6 +3108,7 @@ int mcf_get_result(mcf_handle* h, int32_t* status, int64_t* objective_hi_lo, int
         h->stats.pricing_mode = h->small ? 2 : (h->mid ? 3 : (h->rcached ? 1 : 0));
         h->stats.sweep_variant = ((h->view.vkey && h->opt.rule != MCF_RULE_DEVEX_BLOCK) ? 1 : 0) | (h->view.vkey && h->nt_sweep ? 2 : 0) | (h->view.dirty ? 4 : 0);
         h->stats.tree_blocks = h->bpl ? h->bpl_shift : 0; h->stats.tree_rebuilds = c.rebuilds;
+        h->stats.run_pairs = h->run_pairs;
         h->stats.cycle_scans = c.scans; h->stats.scan_rounds = c.scan_rounds; {
             h->stats.arcs_swept = c.arcs_priced;  // full sweeps read what they cover ...
             if (h->view.dirty) {                   // ... incremental ones count per pricing workgroup

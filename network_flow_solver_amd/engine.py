@@ -57,7 +57,7 @@ class McfOptions(ctypes.Structure):
         ("devex_tuner", ctypes.c_int32), ("devex_stay", ctypes.c_int32), ("forward_first", ctypes.c_int32),
         ("compressed_keys", ctypes.c_int32), ("vkey_half_log2", ctypes.c_int32), ("climb_depth", ctypes.c_int32),
         ("overlap_update", ctypes.c_int32), ("key_mode", ctypes.c_int32), ("arc_priority", ctypes.POINTER(ctypes.c_int8)),
-        ("tree_blocks", ctypes.c_int32), ("tree_pool", ctypes.c_int32), ("rc_drop", ctypes.c_int32), ("pad0", ctypes.c_int32),
+        ("tree_blocks", ctypes.c_int32), ("tree_pool", ctypes.c_int32), ("rc_drop", ctypes.c_int32), ("pivot_run", ctypes.c_int32),
     ]
 
 
@@ -73,6 +73,7 @@ class McfStats(ctypes.Structure):
         ("cycle_scans", ctypes.c_int64), ("scan_rounds", ctypes.c_int64), ("arcs_swept", ctypes.c_int64),
         ("loop_ms", ctypes.c_double), ("loop_launches", ctypes.c_int64), ("sweep_variant", ctypes.c_int64),
         ("tree_blocks", ctypes.c_int64), ("tree_rebuilds", ctypes.c_int64), ("rc_dropped_at", ctypes.c_int64),
+        ("run_pairs", ctypes.c_int64), ("run_left_at", ctypes.c_int64),
     ]
 
     def as_dict(self) -> dict:
@@ -165,7 +166,7 @@ class McfEngine:
                  resident_rc: bool = True, cycle_scan: int = 0, mid_loop: int = 0, full_sweeps: int = 0,
                  devex_tuner: int = 0, devex_stay: bool = False, forward_first: bool = False, compressed_keys: int = 0,
                  vkey_half_log2: int = 0, climb_depth: int = 0, overlap_update: int = 0, key_mode: int = 0, arc_priority=None,
-                 tree_blocks: int = 0, tree_pool: int = 0, rc_drop: int = 0):
+                 tree_blocks: int = 0, tree_pool: int = 0, rc_drop: int = 0, pivot_run: int = 0):
         self._h = None
         lib = load_library()
         if lib.mcf_device_count() <= 0:
@@ -219,6 +220,7 @@ class McfEngine:
         opt.tree_blocks = int(tree_blocks) if tree_blocks else int(os.environ.get("MCF_TREE_BLOCKS", "0"))
         opt.tree_pool = int(tree_pool) if tree_pool else int(os.environ.get("MCF_TREE_POOL", "0"))
         opt.rc_drop = int(rc_drop)   # resident reduced costs given up from this average re-hung subtree size on (0 auto, -1 never)
+        opt.pivot_run = int(pivot_run)   # candidate list on the blocked list: pivots back to back in one workgroup (0 off, k pairs per period)
         if shard is not None:
             opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
         self.rule = rule

@@ -1308,7 +1308,9 @@ def test_candidate_cache_and_reduced_cost_drop(gpu_engine_module):
         emf = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2 | 0x100)
         for layout in (-1, 6):
             for opts in ({}, {"resident_rc": False}, {"full_sweeps": -1}, {"rc_drop": 1}, {"rc_drop": 1, "full_sweeps": -1}, {"use_graph": False, "rc_drop": 2},
-                         {"forward_first": True}, {"batch_pivots": 7, "rc_drop": 1}):
+                         {"forward_first": True}, {"batch_pivots": 7, "rc_drop": 1}, {"pivot_run": 4}, {"pivot_run": 2, "rc_drop": 1}):
+                # (pivot_run: the opt-in run shape -- minor pivots back to back in one workgroup with their updates in place;
+                #  it needs the blocked list and is ignored on the dense layout)
                 ref = emf if opts.get("forward_first") else em
                 with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2, tree_blocks=layout, fused=False, mid_loop=-1, **opts) as eng:
                     for budget in (1, 50, 4999):
@@ -1319,6 +1321,8 @@ def test_candidate_cache_and_reduced_cost_drop(gpu_engine_module):
                 assert res.status == "optimal" and res.objective == ref["objective"] and res.stats["pivots"] == ref["pivots"], (inst.name, layout, opts)
                 assert np.array_equal(res.flow, ref["flow"]) and np.array_equal(res.potential, ref["potential"]) and np.array_equal(tree["order"], ref["order"])
                 assert np.array_equal(rc, inst.cost + tree["pi"][inst.tail] - tree["pi"][inst.head])
+                if "pivot_run" in opts and layout > 0 and "rc_drop" not in opts:
+                    assert res.stats["run_pairs"] > 0 or res.stats["run_left_at"] > 0, (inst.name, opts, res.stats)
                 if "rc_drop" in opts:   # the switch happened (after the first batches) and the handle says so
                     assert 0 < res.stats["rc_dropped_at"] < res.stats["pivots"] and res.stats["pricing_mode"] == 0 and not resident
                 else:
