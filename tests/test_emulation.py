@@ -108,14 +108,17 @@ def _basis_of(inst, res):
 @pytest.mark.parametrize("idx", [0, 1, 2, 3, 5, 6, 7])
 def test_warm_start_from_the_optimal_basis_needs_almost_no_pivots(idx):
     """simplex.py:740-1010: re-installing the final basis of a solve (tree arcs + which non-basic arcs sit at
-    capacity) reproduces the optimal flows by conservation; only wrong-way degenerate arcs the repair
-    step replaced by artificial ones may need a few degenerate pivots."""
+    capacity) reproduces the optimal flows by conservation, and -- since [r3] mcf_apply_basis hangs each component of the
+    basis where the fewest degenerate arcs point the wrong way (none, for a basis taken from a strongly feasible tree) --
+    the optimum is CONFIRMED in zero pivots when the real basic arcs span the nodes (k == 1 artificial arc left in the tree);
+    with k > 1 components the potentials between components may shift and a few degenerate pivots put that right."""
     _, inst = load_synthetic()[idx]
     cold = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply)
     it, au = _basis_of(inst, cold)
     warm = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, warm_in_tree=it, warm_at_upper=au)
     assert warm["warm_applied"] and warm["status"] == "optimal" and warm["objective"] == cold["objective"]
-    assert warm["pivots"] <= max(3, cold["pivots"] // 20)
+    k = inst.n - int(it.sum())
+    assert warm["pivots"] <= 8 * (k - 1), (k, warm["pivots"])
     assert warm["pivots"] == warm["degenerate"]  # the flow was already optimal
     assert np.array_equal(warm["flow"], cold["flow"])
     check_tree_invariants(inst.n, warm["parent"], warm["size"], warm["pos"], warm["order"], warm["depth"], warm["psize"])
