@@ -118,7 +118,7 @@ def test_warm_start_from_the_optimal_basis_needs_almost_no_pivots(idx):
     warm = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, warm_in_tree=it, warm_at_upper=au)
     assert warm["warm_applied"] and warm["status"] == "optimal" and warm["objective"] == cold["objective"]
     k = inst.n - int(it.sum())
-    assert warm["pivots"] <= 8 * (k - 1), (k, warm["pivots"])
+    assert warm["pivots"] == 0 if k == 1 else warm["pivots"] <= max(3, cold["pivots"] // 20), (k, warm["pivots"])
     assert warm["pivots"] == warm["degenerate"]  # the flow was already optimal
     assert np.array_equal(warm["flow"], cold["flow"])
     check_tree_invariants(inst.n, warm["parent"], warm["size"], warm["pos"], warm["order"], warm["depth"], warm["psize"])
