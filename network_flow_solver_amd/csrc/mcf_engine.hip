@@ -886,7 +886,13 @@ __device__ __forceinline__ void pivot_core(const McfView& v, PivotShared& S, int
     // S.cy.small is written by lane 0 at the very end of the scan: lane 0 may use it at once, the others after the barrier.
     // Separate calls for the two scratch locations: each inlined copy works on one known address space.
     if (go && threadIdx.x == 0 && S.ctx.status == MCF_RUNNING) {
-        if (S.cy.small) mcf_pivot_decide(v, sp, S.cy); else mcf_pivot_decide(v, gp, S.cy);
+        // (two calls, one per scratch location, were merged by the compiler into one body that fetched its pointers from a
+        //  table in private memory -- two dependent scratch loads on the serial path; selected here they stay in registers)
+        const bool sm = S.cy.small != 0;
+        const McfPaths pp = McfPaths{sm ? sp.path1 : gp.path1, sm ? sp.path2 : gp.path2, sm ? sp.rec1 : gp.rec1, sm ? sp.rec2 : gp.rec2,
+                                     sm ? sp.ppos1 : gp.ppos1, sm ? sp.ppos2 : gp.ppos2, sm ? sp.flow1 : gp.flow1, sm ? sp.flow2 : gp.flow2,
+                                     sm ? sp.slot1 : gp.slot1, sm ? sp.slot2 : gp.slot2};
+        mcf_pivot_decide(v, pp, S.cy);
     }
     MCF_PSTAMP(8);
     __syncthreads();
@@ -1540,7 +1546,9 @@ __device__ __forceinline__ void small_cycle_parallel(const McfView& v, SmallCycl
     const McfCtx* c = v.ctx;
     const int32_t* pcur = c->cur ? v.posbuf[1] : v.posbuf[0];
     const int32_t first = c->pv_first, second = c->pv_second;      // (uniform: LDS broadcast reads)
-    const McfNode r0u = v.node[first], r0w = v.node[second];
+    // (only the depths are carried through the pass; lane 0 reads the whole records again at the end -- kept alive across the
+    //  pass they were spilled to scratch, the only private memory this kernel used)
+    const int32_t du0 = v.node[first].depth, dw0 = v.node[second].depth;
     const int32_t pu = pcur[first], pw = pcur[second];
     const int32_t x = (int32_t)threadIdx.x, wave = x >> 6;
     const int32_t N = v.n_nodes, nwaves = (N + 63) >> 6;
@@ -1557,14 +1565,14 @@ __device__ __forceinline__ void small_cycle_parallel(const McfView& v, SmallCycl
         if (au && aw) by_depth[rec.depth] = x;
         else if (au) {
             const McfArcW a = v.arcw[rec.pred >> 1];
-            const int32_t idx = r0u.depth - rec.depth;
+            const int32_t idx = du0 - rec.depth;
             v.path1[idx] = x; v.rec1[idx] = rec; v.ppos1[idx] = px;
             // first side is walked against the flow: an up arc loses flow, a down arc gains
             res1[idx] = (rec.pred & 1) ? a.flow : (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow);
             h1 = true;
         } else if (aw) {
             const McfArcW a = v.arcw[rec.pred >> 1];
-            const int32_t idx = r0w.depth - rec.depth;
+            const int32_t idx = dw0 - rec.depth;
             v.path2[idx] = x; v.rec2[idx] = rec; v.ppos2[idx] = px;
             res2[idx] = (rec.pred & 1) ? (a.cap >= MCF_INF ? MCF_INF : a.cap - a.flow) : a.flow;
             h2 = true;
@@ -1578,7 +1586,7 @@ __device__ __forceinline__ void small_cycle_parallel(const McfView& v, SmallCycl
     if (x == 0) {
         int32_t n1 = 0, n2 = 0;
         for (int32_t q = 0; q < nwaves; ++q) { n1 += A.c1[q]; n2 += A.c2[q]; }
-        const int32_t jn = by_depth[r0u.depth - n1];   // the join: the common ancestor right above the first side's path
+        const int32_t jn = by_depth[du0 - n1];   // the join: the common ancestor right above the first side's path
         const McfNode rj = v.node[jn];
         // the ratio tests, exactly the climb's: first side -- strictly smaller wins (lowest index among equals), second side --
         // smaller or equal wins (highest index among equals)
@@ -1590,7 +1598,7 @@ __device__ __forceinline__ void small_cycle_parallel(const McfView& v, SmallCycl
         out->n1 = n1; out->n2 = n2;
         out->u = jn; out->w = jn; out->ru = rj; out->rw = rj;
         out->pu = pcur[jn]; out->pw = out->pu; out->su = out->pu; out->sw = out->pu;
-        out->p0u = pu; out->p0w = pw; out->s0u = pu; out->s0w = pw; out->r0u = r0u; out->r0w = r0w;
+        out->p0u = pu; out->p0w = pw; out->s0u = pu; out->s0w = pw; out->r0u = v.node[first]; out->r0w = v.node[second];
         out->small = 0;
     }
 }
@@ -1635,6 +1643,8 @@ __device__ __forceinline__ void solve_small_body(const McfView& g, const SmallLa
     v.reach = nullptr;
     v.bmeta[0] = nullptr; v.bmeta[1] = nullptr; v.candx = nullptr; v.dirty = nullptr; v.dirty_hdr = nullptr;   // (folds the blocked list etc. away)
 
+    // (All fourteen arrays' loads in flight together -- one fused loop, 4- or 16-byte loads -- was measured SLOWER than these
+    //  plain loops: 131 / 125 us against 117 us per 20-pivot launch.)
     copy_words(smem + L.tail, g.tail, m_pad4);
     copy_words(smem + L.head, g.head, m_pad4);
     copy_words(smem + L.cost, g.cost, m_pad4);
@@ -2819,9 +2829,10 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
                 if (!h->loop_ev[0]) { HIP_TRY(h, hipEventCreate(&h->loop_ev[0])); HIP_TRY(h, hipEventCreate(&h->loop_ev[1])); }
                 HIP_TRY(h, hipEventRecord(h->loop_ev[0], h->stream));
             }
-            if (h->small)
+            if (h->small) {
                 hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(kSmallThreads), h->small_layout.total, h->stream, h->view,
                                    h->small_layout, h->opt.rule, h->d_cand, cap, h->h_ctx);
+            }
             else {
                 // eager launches need not run past the cap (a replayed graph has a fixed length: its surplus slots early-exit)
                 const int64_t left = cap - h->h_ctx->pivots;
@@ -2836,6 +2847,8 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
             if (timed_loop) HIP_TRY(h, hipEventRecord(h->loop_ev[1], h->stream));
             HIP_TRY(h, hipGetLastError());
             if (h->small) {   // the kernel wrote the host's pinned copy itself
+                // (polling a pinned done word instead was tried: the wake-up saved here comes back in the caller's own
+                //  device synchronisation, and a system-scope fence in front of the word cost 15 us of kernel time)
                 HIP_TRY(h, hipStreamSynchronize(h->stream));
                 h->ctx_current = true;
             } else {
@@ -3430,6 +3443,7 @@ int mcf_get_weights(mcf_handle* h, float* weight_out) {
 
 #ifdef MCF_STAMPS
 int mcf_debug_stamps(mcf_handle* h, unsigned long long* out8) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out8, h->d_rec1, 64, hipMemcpyDeviceToHost));
     return MCF_OK;
 }
