@@ -829,7 +829,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce(const McfCand* __rest
 #ifdef MCF_STAMPS
 __device__ unsigned long long g_pivot_stamps[24];
 #endif
-constexpr int kHitsLds = 4096;  // hit-list entries kept in LDS (a longer cycle spills to global scratch)
+constexpr int kHitsLds = 2048;  // hit-list entries (8 bytes each) kept in LDS (a longer cycle spills to global scratch)
 constexpr int kSmallPath = 512;  // cycles up to this many nodes are recorded in LDS instead of the global path scratch
 
 // LDS state of one pivoting workgroup (k_pivot, k_solve_mid)
@@ -2495,8 +2495,9 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     if ((e = dalloc(&h->d_pi, N)) != hipSuccess) return fail("hipMalloc pi", e);
     if ((e = dalloc(&h->d_node, N)) != hipSuccess) return fail("hipMalloc node", e);
     const size_t bpl_slots = h->bpl ? ((size_t)h->bpl_cap << h->bpl_shift) + 4 : 0;   // slots per arena (+4: groups of four)
-    if ((e = dalloc(&h->d_order0, h->bpl ? bpl_slots : N)) != hipSuccess) return fail("hipMalloc order", e);
-    if ((e = dalloc(&h->d_order1, h->bpl ? bpl_slots : N)) != hipSuccess) return fail("hipMalloc order", e);
+    // (+4: the cycle scan reads the nodes in aligned groups of four, like the sizes)
+    if ((e = dalloc(&h->d_order0, h->bpl ? bpl_slots : N + 4)) != hipSuccess) return fail("hipMalloc order", e);
+    if ((e = dalloc(&h->d_order1, h->bpl ? bpl_slots : N + 4)) != hipSuccess) return fail("hipMalloc order", e);
     if ((e = dalloc(&h->d_pos0, N)) != hipSuccess) return fail("hipMalloc pos", e);
     if ((e = dalloc(&h->d_pos1, h->bpl ? 1 : N)) != hipSuccess) return fail("hipMalloc pos", e);
     if ((e = dalloc(&h->d_path1, N)) != hipSuccess) return fail("hipMalloc path", e);

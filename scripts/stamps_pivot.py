@@ -31,6 +31,10 @@ for case in CASES:
               f"(solve {1e6 * st['solve_seconds'] / max(st['pivots'], 1):.2f} us/pivot; tree_blocks {st['tree_blocks']} rebuilds {st['tree_rebuilds']} rc dropped at {st['rc_dropped_at']})")
         for n, x in zip(names, v[:11]):
             print(f"   {n:22s} per launch {x / launches:9.1f}  share {100 * x / v[:11].sum():5.1f}%", flush=True)
+        if v[20] > 0:
+            print(f"   scan: coarse pass         per launch {v[21] / launches:9.1f}   (not in the shares above; 'scan: rounds' is the fine pass alone when this is non-zero)")
+            print(f"   scans {int(v[20])} ({100 * v[20] / launches:.0f}% of launches): blocks in the coarse pass {v[17] / v[20]:.0f}, flagged {v[18] / v[20]:.1f}, "
+                  f"one-sided ancestors found {v[19] / v[20]:.1f} per scan", flush=True)
         done = st["pivots"]
         if st["status"] != "iteration_limit":
             break
