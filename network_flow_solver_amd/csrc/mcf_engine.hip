@@ -1932,6 +1932,7 @@ struct mcf_handle {
     int graph_batch = 0;
     // overlapped graphs: pricing of pivot t+1 runs beside the tree permutation of pivot t (needs only the reduced-cost half)
     bool overlap = false;
+    bool overlap_cfg = false;   // what mcf_create decided (dropping the reduced costs turns it off until the next reset)
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork_ev;   // two per slot: pivot done (main -> side), priced (side -> main)
     // profiling events
@@ -2057,6 +2058,7 @@ int upload_image(mcf_handle* h) {
     if (h->rc_dropped) {   // a fresh start keeps the reduced costs resident again
         h->rc_dropped = false;
         h->rcached = true;
+        h->overlap = h->overlap_cfg;
         h->view.rcache = h->d_rcache; h->view.vkey = h->d_vkey; h->view.dirty = h->d_dirty;
         if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
         if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -2661,6 +2663,7 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     {
         const bool able = !h->bpl && h->rcached && !h->small && !h->mid && h->shards == 1 && !opt.profile && opt.rule != MCF_RULE_CANDIDATE_LIST;
         h->overlap = able && opt.overlap_update > 0;
+        h->overlap_cfg = h->overlap;
         if (h->overlap && (e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     }
     // compressed Dantzig keys for the grid sweeps of the Dantzig / candidate-list rules (4 B per arc instead of 9)
@@ -2893,6 +2896,7 @@ int mcf_solve(mcf_handle* h, int64_t max_pivots, mcf_progress_cb cb, void* user,
                     if (ds >= dp * h->rc_drop_subtree) {
                         h->rc_dropped = true;
                         h->rcached = false;
+                        h->overlap = false;   // (two-stream graphs price beside the permutation: only valid from resident values)
                         h->view.rcache = nullptr; h->view.vkey = nullptr; h->view.dirty = nullptr;
                         h->stats.rc_dropped_at = h->h_ctx->pivots;
                         if (graph) {

@@ -35,6 +35,16 @@ for wl in netgen_1m_16m netgen_6m_96m netgen_8_08a; do
   (cd $R && python scripts/pmc_summarize.py $O/pmc_${wl}_FETCH_SIZE $O/pmc_${wl}_WRITE_SIZE > $O/pmc_$wl.txt)
   rm -rf $O/pmc_${wl}_FETCH_SIZE $O/pmc_${wl}_WRITE_SIZE
 done
+# the tree update at 1 M nodes (candidate list, blocked preorder list): k_pivot / k_update_bpl over the first 3 000 pivots
+cd /tmp && export TMPDIR=/tmp
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  out=$O/pmc_update_1m_$ctr
+  rm -rf $out
+  MCF_USE_GRAPH=0 WL=netgen_1m_16m RULE=2 FULL_SWEEPS=0 PIVOTS=3000 REPS=1 timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 $R/scripts/pmc_sweep.py > $O/pmc_update_1m_$ctr.log 2>&1
+  echo "pmc update 1m $ctr exit=$?"; tail -1 $O/pmc_update_1m_$ctr.log
+done
+(cd $R && python scripts/pmc_summarize.py $O/pmc_update_1m_FETCH_SIZE $O/pmc_update_1m_WRITE_SIZE > $O/pmc_update_netgen_1m_16m_candidate_list.txt)
+rm -rf $O/pmc_update_1m_FETCH_SIZE $O/pmc_update_1m_WRITE_SIZE
 cd $R
 timeout -k 10 500 python scripts/solve_times.py > $O/solve_times.out 2>&1; echo "solve_times exit=$?"; cp gpurun_out/solve_times.json $O/solve_times.json
 ;; esac

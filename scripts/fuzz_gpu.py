@@ -32,7 +32,9 @@ while time.time() < t_end and runs < max_runs:
                 climb_depth=rng.choice([-1, 0, 0, 2, 9]),                                   # depth gate of the cycle search
                 compressed_keys=rng.choice([-1, 1, 1]), vkey_half_log2=rng.choice([0, 0, 9, 14]),   # key codes, narrow levels
                 key_mode=rng.choice([0, 0, 0, 1, 2, 3]) if rule != 1 else 0,                 # the specialised entering rules' keys
-                overlap_update=rng.choice([0, 0, 1]))                                        # two-stream graphs
+                overlap_update=rng.choice([0, 0, 1]),                                        # two-stream graphs
+                tree_blocks=rng.choice([0, 0, -1, 6, 7]), tree_pool=rng.choice([0, 0, 2, 40]),  # [r3] blocked preorder list, small pools (rebuilds)
+                rc_drop=rng.choice([0, 0, -1, 1, 3]), pivot_run=rng.choice([0, 0, 0, 3]))       # [r3] reduced costs given up mid-solve, run shape
     prio = np.random.default_rng(seed).integers(0, 4, size=len(inst.tail)).astype(np.int8) if opts["key_mode"] == 2 else None
     opts["arc_priority"] = prio
     cost = inst.cost * rng.choice([1, 1, 300])                                               # x300: big-M >= 2^29 (level coding)

@@ -1330,6 +1330,15 @@ def test_candidate_cache_and_reduced_cost_drop(gpu_engine_module):
                     assert 0 < res.stats["rc_dropped_at"] < res.stats["pivots"] and res.stats["pricing_mode"] == 0 and not resident
                 else:
                     assert res.stats["rc_dropped_at"] == 0
+        # Devex gives its reduced costs up too when asked to; a two-stream graph (pricing beside the permutation) is only valid
+        # from resident values and ends with them (found by scripts/fuzz_gpu.py: 3 of 130 runs diverged before that was enforced)
+        emd = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=1)
+        for opts in ({"rc_drop": 1}, {"rc_drop": 1, "overlap_update": 1}, {"rc_drop": 3, "overlap_update": 1, "batch_pivots": 32}):
+            with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=1, fused=False, mid_loop=-1, **opts) as eng:
+                eng.solve()
+                res, tree = eng.result(), eng.tree()
+            assert res.status == "optimal" and res.stats["pivots"] == emd["pivots"] and res.stats["rc_dropped_at"] > 0, (inst.name, opts, res.stats["pivots"], emd["pivots"])
+            assert np.array_equal(res.flow, emd["flow"]) and np.array_equal(res.potential, emd["potential"]) and np.array_equal(tree["order"], emd["order"])
         # a reset brings the resident reduced costs back
         with e.McfEngine(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=2, rc_drop=1, fused=False, mid_loop=-1) as eng:
             eng.solve()
