@@ -630,7 +630,8 @@ MCF_HD McfPaths mcf_view_paths(const McfView& v) {
 // One-sided ancestor noted by the scan rounds: (preorder position << 1) | side.  (Fetching the node record right
 // in the round was measured and lost: the wave that finds a hit stalls on two dependent loads per hit while the
 // other waves wait for it at the round's barrier -- rounds 5.3 K -> 11.1 K ticks on netgen_8_14a.)
-struct McfHit { int32_t slot_side, node; };   // ... and the node there (read with the sizes: the hit pass starts at its record)
+typedef int32_t McfHit;   // (carrying the node id along -- read together with the sizes -- was tried in round 3: it spares the hit pass a
+                          //  dependent load but doubles the bytes of the fine pass, which is bound by one CU's memory pipeline: net slower)
 
 // State of the cycle search, shared by the climb (one lane) and the scan (the whole team).
 struct McfCycle {
@@ -926,10 +927,10 @@ MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_
     const McfBlkMeta* bm = v.ctx->cur ? v.bmeta[1] : v.bmeta[0];
     const int32_t bs = v.blk_shift, bmask = (1 << bs) - 1;
     for (int32_t t = lane; t < nhits; t += nlanes) {
-        McfHit hrec;
-        if (t < hits_cap) hrec = hits[t]; else hrec = spill[t - hits_cap];
-        const int32_t slot_side = hrec.slot_side, slot = slot_side >> 1;
-        const int32_t node = hrec.node;   // (was ord[slot]: one more dependent round trip in front of the record)
+        int32_t slot_side;
+        if (t < hits_cap) slot_side = hits[t]; else slot_side = spill[t - hits_cap];
+        const int32_t slot = slot_side >> 1;
+        const int32_t node = ord[slot];
         // blocked list: the logical position from the block's base (independent of the node load: same round trip)
         const int32_t pos = bpl ? bm[slot >> bs].base + (slot & bmask) : slot;
         const McfNode rec = v.node[node];
@@ -963,7 +964,7 @@ MCF_HD void mcf_scan_hit_pass(const McfView& v, const McfPaths& pb, const int32_
 // global round trip per look-up.  The caller has run mcf_scan_init(acc) before the barrier in front of this call.
 // Four consecutive positions i0 .. i0 + 3 with their subtree sizes: note the ancestors of the node at position pu
 // and / or pw among them (common ancestor -> jpos, one-sided -> hit list).
-MCF_HD void mcf_scan_group(int32_t i0, int32_t s0, const int32_t* sz, const int32_t* nd, int32_t pu, int32_t pw, int32_t pmin, int64_t* jpos_slot,
+MCF_HD void mcf_scan_group(int32_t i0, int32_t s0, const int32_t* sz, int32_t pu, int32_t pw, int32_t pmin, int64_t* jpos_slot,
                            McfScanAcc* acc, McfHit* hits, int32_t hits_cap, McfHit* spill, bool dense) {
     // Cheap reject of the whole group first: a subtree can hold pu or pw only if it reaches past the lower
     // of the two, and almost every position is a small subtree far to the left of both.
@@ -1000,13 +1001,13 @@ MCF_HD void mcf_scan_group(int32_t i0, int32_t s0, const int32_t* sz, const int3
             if (lane_id == leader) base = atomicAdd(&acc->nhits, (int)__popcll(hm));
             base = __shfl(base, leader);
             const int32_t slot = base + (int32_t)__popcll(hm & ((1ull << lane_id) - 1ull));
-            const McfHit hrec = McfHit{((s0 + e) << 1) | (aw ? 1 : 0), nd[e]};
+            const McfHit hrec = ((s0 + e) << 1) | (aw ? 1 : 0);
             if (slot < hits_cap) hits[slot] = hrec; else spill[slot - hits_cap] = hrec;
         }
 #else
         if (hit) {
             const int32_t slot = MCF_ATOMIC_ADD32(&acc->nhits, 1);
-            const McfHit hrec = McfHit{((s0 + e) << 1) | (aw ? 1 : 0), nd[e]};
+            const McfHit hrec = ((s0 + e) << 1) | (aw ? 1 : 0);
             if (slot < hits_cap) hits[slot] = hrec; else spill[slot - hits_cap] = hrec;
         }
 #endif
@@ -1120,7 +1121,7 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
             // (a long cycle flags hundreds of blocks; one block per trip made the pass a chain of dependent round trips)
             for (int32_t t0 = g; t0 < nf; t0 += ngroups * MCF_SCAN_GROUPS) {
                 for (int32_t q = 0; q < nsub; ++q) {
-                    int32_t szk[MCF_SCAN_GROUPS][4], ndk[MCF_SCAN_GROUPS][4], s0k[MCF_SCAN_GROUPS], i0k[MCF_SCAN_GROUPS];
+                    int32_t szk[MCF_SCAN_GROUPS][4], s0k[MCF_SCAN_GROUPS], i0k[MCF_SCAN_GROUPS];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -1128,7 +1129,6 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
                         const int32_t t = t0 + k * ngroups;
                         s0k[k] = -1; i0k[k] = 0;
                         szk[k][0] = szk[k][1] = szk[k][2] = szk[k][3] = 0;
-                        ndk[k][0] = ndk[k][1] = ndk[k][2] = ndk[k][3] = 0;
                         if (t >= nf) continue;
                         int32_t b, lbase;
                         if (t < MCF_SCAN_BLK_CAP) { b = acc->blk[t]; lbase = acc->blkbase[t]; }
@@ -1137,18 +1137,16 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
                         i0k[k] = lbase + (sub0 + q) * 4;           // their logical positions
 #if defined(__HIP_DEVICE_COMPILE__)
                         const int4 w4 = *reinterpret_cast<const int4*>(psz + s0k[k]);
-                        const int4 n4 = *reinterpret_cast<const int4*>(ord + s0k[k]);   // the nodes ride along (same round trip)
                         szk[k][0] = w4.x; szk[k][1] = w4.y; szk[k][2] = w4.z; szk[k][3] = w4.w;
-                        ndk[k][0] = n4.x; ndk[k][1] = n4.y; ndk[k][2] = n4.z; ndk[k][3] = n4.w;
 #else
-                        for (int e = 0; e < 4; ++e) { szk[k][e] = psz[s0k[k] + e]; ndk[k][e] = (bpl || s0k[k] + e < v.n_nodes) ? ord[s0k[k] + e] : 0; }
+                        for (int e = 0; e < 4; ++e) szk[k][e] = psz[s0k[k] + e];
 #endif
                     }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
                     for (int k = 0; k < MCF_SCAN_GROUPS; ++k)
-                        if (s0k[k] >= 0) mcf_scan_group(i0k[k], s0k[k], szk[k], ndk[k], pu, pw, pmin, &acc->jpos[0], acc, hits, hits_cap, spill, !bpl);
+                        if (s0k[k] >= 0) mcf_scan_group(i0k[k], s0k[k], szk[k], pu, pw, pmin, &acc->jpos[0], acc, hits, hits_cap, spill, !bpl);
                 }
             }
             MCF_TEAM_BARRIER();
@@ -1164,7 +1162,7 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
     int32_t par = 0;
     while (!done) {
         const int32_t lo = top - nlanes * 4 * MCF_SCAN_GROUPS;
-        int32_t sz[MCF_SCAN_GROUPS][4], nd[MCF_SCAN_GROUPS][4];
+        int32_t sz[MCF_SCAN_GROUPS][4];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -1172,16 +1170,13 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
             const int32_t slice = lo + k * nlanes * 4;  // uniform
             const int32_t i = slice + lane * 4;
             sz[k][0] = sz[k][1] = sz[k][2] = sz[k][3] = 0;
-            nd[k][0] = nd[k][1] = nd[k][2] = nd[k][3] = 0;
             if (slice + nlanes * 4 <= 0) continue;      // the whole slice lies below position 0 (small trees: most do)
             if (i >= 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 const int4 q = *reinterpret_cast<const int4*>(psz + i);
-                const int4 n4 = *reinterpret_cast<const int4*>(ord + i);   // (order[] is padded like psz[])
                 sz[k][0] = q.x; sz[k][1] = q.y; sz[k][2] = q.z; sz[k][3] = q.w;
-                nd[k][0] = n4.x; nd[k][1] = n4.y; nd[k][2] = n4.z; nd[k][3] = n4.w;
 #else
-                for (int e = 0; e < 4; ++e) { sz[k][e] = psz[i + e]; nd[k][e] = i + e < v.n_nodes ? ord[i + e] : 0; }
+                for (int e = 0; e < 4; ++e) sz[k][e] = psz[i + e];
 #endif
             }
         }
@@ -1191,7 +1186,7 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
         for (int k = 0; k < MCF_SCAN_GROUPS; ++k) {
             const int32_t slice = lo + k * nlanes * 4;
             if (slice + nlanes * 4 <= 0) continue;
-            mcf_scan_group(slice + lane * 4, slice + lane * 4, sz[k], nd[k], pu, pw, pmin, &acc->jpos[par], acc, hits, hits_cap, spill, true);
+            mcf_scan_group(slice + lane * 4, slice + lane * 4, sz[k], pu, pw, pmin, &acc->jpos[par], acc, hits, hits_cap, spill, true);
         }
         MCF_TEAM_BARRIER();
         // the next round's atomics go to the other slot: nobody can overtake a lane still reading this one
@@ -1214,6 +1209,8 @@ MCF_HD void mcf_pivot_scan(const McfView& v, const McfPaths& sp, int32_t small_c
         mcf_stamp_acc[18] += (unsigned long long)acc->nblk;
         mcf_stamp_acc[19] += (unsigned long long)nhits;
         mcf_stamp_acc[20] += 1;
+        if (acc->nblk > 128) mcf_stamp_acc[22] += 1;   // fine passes that need more than one trip ...
+        if (acc->nblk > 512) mcf_stamp_acc[11] += 1;   // ... more than four
     }
 #endif
     if (lane == nlanes - 1) {  // the join's record rides along with the hit pass (this lane is the last to get a hit)

@@ -829,7 +829,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce(const McfCand* __rest
 #ifdef MCF_STAMPS
 __device__ unsigned long long g_pivot_stamps[24];
 #endif
-constexpr int kHitsLds = 2048;  // hit-list entries (8 bytes each) kept in LDS (a longer cycle spills to global scratch)
+constexpr int kHitsLds = 4096;  // hit-list entries kept in LDS (a longer cycle spills to global scratch)
 constexpr int kSmallPath = 512;  // cycles up to this many nodes are recorded in LDS instead of the global path scratch
 
 // LDS state of one pivoting workgroup (k_pivot, k_solve_mid)

@@ -34,7 +34,7 @@ for case in CASES:
         if v[20] > 0:
             print(f"   scan: coarse pass         per launch {v[21] / launches:9.1f}   (not in the shares above; 'scan: rounds' is the fine pass alone when this is non-zero)")
             print(f"   scans {int(v[20])} ({100 * v[20] / launches:.0f}% of launches): blocks in the coarse pass {v[17] / v[20]:.0f}, flagged {v[18] / v[20]:.1f}, "
-                  f"one-sided ancestors found {v[19] / v[20]:.1f} per scan", flush=True)
+                  f"one-sided ancestors found {v[19] / v[20]:.1f} per scan; scans with > 128 flagged blocks {100 * v[22] / v[20]:.1f}%, > 512: {100 * v[11] / v[20]:.1f}%", flush=True)
         done = st["pivots"]
         if st["status"] != "iteration_limit":
             break
