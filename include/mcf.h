@@ -135,7 +135,7 @@ typedef struct mcf_options {
     int32_t rc_drop;         /* resident reduced costs are given up in mid-solve -- pricing then gathers the potentials, as with no_rcache --
                                 once the re-hung subtrees average more than this many nodes over a batch of pivots: from there on the
                                 patch of the incident arcs' reduced costs costs more per pivot than the dearer sweeps.  0 = auto
-                                (candidate list from 100 000 nodes on: 384; else never), -1 = never, k > 0 = that threshold (candidate
+                                (from 100 000 nodes on: candidate list 384, Devex 1 500; else never), -1 = never, k > 0 = that threshold (candidate
                                 list and Devex; the Dantzig rule sweeps every arc on every pivot and never drops).  Same pivots. */
     int32_t pivot_run;       /* candidate-list handles on the blocked list: a list period is one sweep + this many pairs of (k_pivot_run:
                                 pivots back to back in ONE workgroup, each followed by its update in place, until an update is too large

@@ -2720,12 +2720,15 @@ int mcf_create(int32_t n, int64_t m, const int32_t* tail, const int32_t* head, c
     h->rc_able = h->rcached;
     {
         // auto: candidate lists (one sweep per ~33 pivots) on large instances (from 100 000 nodes: measured at 1 M / 16 M) from an
-        // average |T2| of 384 nodes; on request for Devex; never for the Dantzig rule, whose every pivot sweeps all arcs, for
+        // average |T2| of 384 nodes, Devex there from 1 500; never for the Dantzig rule, whose every pivot sweeps all arcs, for
         // shards (their driver owns the launches) or the persistent loops.  rc_drop: -1 = never, k > 0 = that threshold.
         int64_t thr = 0;
         if (h->rcached && !h->mid && !h->small && h->shards == 1 && opt.key_mode == 0 && !opt.forward_first) {
             if (opt.rc_drop > 0) thr = opt.rc_drop;
-            else if (opt.rc_drop == 0) thr = (opt.rule == MCF_RULE_CANDIDATE_LIST && im.n_nodes >= 100000) ? 384 : 0;
+            else if (opt.rc_drop == 0 && im.n_nodes >= 100000)
+                // (Devex block search sweeps one block per pivot: the dearer sweep is paid every time, so it waits for larger
+                //  subtrees -- 1 M / 16 M: 139.8 s without, 134.0 / 134.8 s with a threshold of 1 500 / 384)
+                thr = opt.rule == MCF_RULE_CANDIDATE_LIST ? 384 : (opt.rule == MCF_RULE_DEVEX_BLOCK ? 1500 : 0);
             if (opt.rule == MCF_RULE_DANTZIG_FULL) thr = 0;
         }
         if (const char* env = std::getenv("MCF_RC_DROP")) { const long vv = std::atol(env); thr = vv > 0 ? vv : 0; }   // A/B switch
