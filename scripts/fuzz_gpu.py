@@ -80,7 +80,7 @@ while time.time() < t_end and runs < max_runs:
             fh.write(msg + "\n")
     prev_cfg = {"seed": seed, "family": fam, "n": inst.n, "rule": rule, "opts": {k: v for k, v in opts.items() if k != "arc_priority"}, "cap": cap}
     seed += 1
-    if runs % 50 == 0:
+    if runs % 10 == 0:
         print(f"  ... {runs} runs, {fails} mismatches, {t_end - time.time():.0f} s left", flush=True)   # (a silent GPU command is killed)
 print(json.dumps({"runs": runs, "fails": fails, "last_seed": seed - 1}))
 sys.exit(1 if fails else 0)
