@@ -61,6 +61,26 @@ def test_no_gpu_means_loud_failure_not_fallback():
         engine.McfEngine(2, [0], [1], [1], [1], [1, -1])
 
 
+def test_bench_without_a_gpu_fails_loudly_and_its_ranks_do_not_wait_for_each_other():
+    """`bench.py --gpus 2` without a launcher spawns its two ranks; a rank that dies would leave the other waiting in its
+    first collective for ever, so the spawner polls its children and ends the rest as soon as one has failed.  Here (no GPU)
+    every rank fails at once: the call must come back promptly with a non-zero exit code and no JSON line -- never a number
+    from some CPU path."""
+    import subprocess
+    import sys
+    import time
+
+    if engine.device_count() > 0:
+        pytest.skip("a GPU is visible: the failure path is not what runs here")
+    for extra in (["--gpus", "2"], []):
+        t0 = time.time()
+        proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), *extra, "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-point"],
+                              capture_output=True, text=True, timeout=240)
+        assert proc.returncode != 0, (extra, proc.stdout[-300:])
+        assert '"metric"' not in proc.stdout, proc.stdout[-300:]
+        assert time.time() - t0 < 200
+
+
 def test_flatten_matches_reference_ordering_and_shift():
     case = next(c for c in CASES if c["name"] == "lower_bounds_and_parallel")
     p = nfs.build_problem(case["nodes"], case["arcs"], True, 1e-6)
