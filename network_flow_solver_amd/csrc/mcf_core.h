@@ -744,7 +744,7 @@ MCF_HD bool mcf_pivot_begin_t(const McfView& v, int64_t best_key, int64_t best_a
 
     // ---- then what hangs on the end points, all independent of each other: one more round trip
     int64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    const bool adjp = MCF_HAS_BPL(v) && v.rcache;
+    const bool adjp = v.rcache && v.adj_off;   // ([r3] both layouts: the dense update's patch starts from the range too)
     if (adjp) {
         // the re-hung subtree contains exactly one end point of the entering arc; when it is that node alone (most pivots of
         // a large sparse instance) the update's reduced-cost patch can start from here instead of looking the node up
@@ -1375,6 +1375,11 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycl
     c->pending_flip = 1;
     c->subtree_nodes += S;
     c->stage = 2;
+    if (S == 1) {   // T2 = {u_in}: first (stem on the first side) or second (the adjacency range only rides along with resident reduced costs)
+        c->pv_t2n = 1;
+        c->pv_t2node = result == 1 ? first : second;
+        if (result != 1) { c->pv_adj[0] = c->pv_adj[2]; c->pv_adj[1] = c->pv_adj[3]; }
+    }
     if (MCF_HAS_BPL(v)) {
         // blocked list: T2 goes into fresh blocks (dense-packed), in front of them two blocks for what has to be cut off
         // existing blocks; nothing else moves.  The pool is a bump allocator: when it runs out, this pivot's update writes
@@ -1382,11 +1387,6 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycl
         c->t_ins = t;
         c->nchg = 0;   // (shrunken subtrees are flagged in bext[], not listed)
         c->t2_blk = (result == 1 ? pp.slot1 : pp.slot2)[k] >> v.blk_shift;
-        if (S == 1) {   // T2 = {u_in}: first (stem on the first side) or second (the adjacency range only rides along with resident reduced costs)
-            c->pv_t2n = 1;
-            c->pv_t2node = result == 1 ? first : second;
-            if (result != 1) { c->pv_adj[0] = c->pv_adj[2]; c->pv_adj[1] = c->pv_adj[3]; }
-        }
         // inserted directly behind v_in: the cut, if any, is in v_in's block; at the end of v_in's subtree: wherever that is
         c->ins_blk = t == tA ? ((result == 1 ? cy.s0w : cy.s0u) >> v.blk_shift) : -1;
         const int32_t need = MCF_BLK_COPIES + ((S + (1 << v.blk_shift) - 1) >> v.blk_shift);

@@ -523,6 +523,23 @@ __device__ __forceinline__ void rcupd_pass(const McfView& v, const McfCtx& c, in
     const int64_t* __restrict__ adj_off = v.adj_off;
     const int64_t* __restrict__ adj = v.adj;
     int64_t* __restrict__ rcache = v.rcache;
+    if (c.pv_t2n == 1) {
+        // [r3] T2 is the one node the pivot kernel named, and its adjacency range came along with the control block: control
+        // block -> adjacency -> reduced cost, instead of -> order -> adjacency offsets -> adjacency -> other end's position ->
+        // reduced cost (the longest chain of the launch on the first pivots of a cold start, when almost every T2 is one node)
+        if (group != 0) return;
+        const int32_t node = c.pv_t2node;
+        for (int64_t p = c.pv_adj[0] + sub; p < c.pv_adj[1]; p += 16) {
+            const int64_t ent = adj[p];
+            if ((int32_t)(ent >> 32) == node) continue;  // a loop: both ends inside T2
+            const int32_t e = (int32_t)((uint32_t)ent >> 1);
+            const int64_t r = rcache[e] + ((ent & 1) ? sigma : -sigma);
+            rcache[e] = r;
+            if (v.vkey) v.vkey[e] = mcf_vkey(-(int64_t)v.state[e] * r, v.vk_bigm, v.vk_half);
+            mcf_mark_dirty(v, e);
+        }
+        return;
+    }
     for (int64_t t = group; t < S; t += ngroups) {
         const int32_t u = ord[a0 + t];
         const int64_t beg = adj_off[u], end = adj_off[u + 1];
@@ -548,7 +565,7 @@ __device__ __forceinline__ void candx_pass(const McfView& v, const McfCtx& c, in
     const bool bpl = MCF_HAS_BPL(v);
     const int32_t a0 = c.t2_old, S = c.t2_size;
     const int32_t* __restrict__ pold = c.cur ? v.posbuf[1] : v.posbuf[0];  // dense array: old positions
-    const bool one = bpl && c.pv_t2n == 1;
+    const bool one = c.pv_t2n == 1;   // (either layout)
     for (int32_t i = tid; i < v.ncandx; i += stride) {
         McfCandX x = v.candx[i];
         if (x.arc < 0) continue;
