@@ -267,6 +267,7 @@ struct McfCtx {
     int32_t pv_t2node;         //   rides along, fetched while the cycle was searched), 0 = the update finds T2's nodes itself
     int64_t pv_adj[4];         // adjacency ranges [beg, end) of the entering arc's end points: first, second
     int32_t dense_blocks;      // blocks a dense list needs: ceil(n_nodes / block)
+    int32_t pv_dd0;            // depth change of the first piece of the re-rooted subtree (all of it when pv_k == 0: nseg == 1)
     int64_t rebuilds;          // (diagnostic)
 };
 
@@ -1357,6 +1358,9 @@ MCF_HD void mcf_pivot_decide(const McfView& v, const McfPaths& pp, const McfCycl
     const McfNode rvin = result == 1 ? cy.r0w : cy.r0u;
     const int32_t pvin = result == 1 ? cy.p0w : cy.p0u;
     c->pv_vin_depth = rvin.depth;
+    // depth change of the first piece of the re-rooted subtree (u_in and what hangs below it): with k == 0 that piece is all
+    // of T2 and the segment table is {t2_new, t2_old, S, this} -- the apply pass then needs no look-up in it (mcf_apply_source)
+    c->pv_dd0 = rvin.depth + 1 - (result == 1 ? cy.r0u : cy.r0w).depth;
     // insertion point in OLD coordinates: directly behind v_in, or at the end of
     // v_in's block -- whichever moves fewer array elements
     const int32_t tA = pvin + 1, tB = pvin + rvin.size;
@@ -1793,6 +1797,10 @@ MCF_HD int32_t mcf_apply_source(const McfCtx& c, const McfSeg* seg, int32_t j, b
     const int32_t b = c.t2_new, S = c.t2_size, a0 = c.t2_old;
     if (j >= b && j < b + S) {
         *in_t2 = true;
+        if (c.nseg == 1) {   // (the leaving arc is u_in's own tree arc: one piece, described by the control block alone)
+            *ddepth = c.pv_dd0;
+            return a0 + (j - b);
+        }
         int32_t lo = 0, hi = c.nseg - 1;  // last segment with dst <= j
         while (lo < hi) {
             const int32_t mid = (lo + hi + 1) >> 1;
