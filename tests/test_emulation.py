@@ -316,3 +316,41 @@ def test_blocked_list_after_every_pivot_and_on_a_warm_start():
                              warm_at_upper=(cold["flow"] == inst.cap) & (inst.cap > 0) & ~cold["in_tree"].astype(bool))
     assert warm["warm_applied"] and warm["status"] == "optimal" and warm["objective"] == cold["objective"]
     check_tree_invariants(inst.n, warm["parent"], warm["size"], warm["pos"], warm["order"], warm["depth"], warm["psize"])
+
+
+def test_random_instances_blocked_list_equals_dense_array_and_optimal_bases_need_no_pivots():
+    """A small slice of scripts/fuzz_cpu_layout.py and scripts/fuzz_cpu_warm.py (which ran 3 226 / 4 333 cases for
+    profiles/r03_fuzz_and_layout_checks.txt): on random seeded instances the emulation on the blocked preorder list (random
+    block size, random pool incl. none) equals the emulation on the dense array in everything, and a warm start from the
+    optimal basis -- real arcs only, as a Basis hands it over (simplex.py:1744-1765) -- is confirmed in ZERO pivots when the
+    real basic arcs span the nodes."""
+    import random
+
+    from network_flow_solver_amd import generators
+
+    zero = 0
+    for seed in range(5000, 5060):
+        rng = random.Random(seed)
+        n = rng.choice([12, 40, 90, 250])
+        fam = rng.choice(["netgen", "gridgen", "goto"])
+        if fam == "netgen":
+            inst = generators.netgen_style(n, n * rng.choice([3, 6, 10]), seed=seed)
+        else:
+            w = max(3, int(n ** 0.5))
+            inst = (generators.gridgen_style if fam == "gridgen" else generators.goto_style)(w, w, seed=seed)
+        rule = rng.choice([0, 1, 2])
+        dense = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule)
+        bits = rule | (rng.choice([2, 3, 4, 5]) << 16) | (rng.choice([0, 1, 2, 9]) << 20)   # emul_engine.cpp: decode_rule
+        blk = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=bits)
+        assert dense["status"] == blk["status"] and dense["pivots"] == blk["pivots"] and dense["objective"] == blk["objective"], (seed, bits)
+        for k in ("flow", "potential", "order", "pos", "psize", "depth", "parent"):
+            assert np.array_equal(dense[k], blk[k]), (seed, bits, k)
+        if dense["status"] != "optimal":
+            continue
+        it, au = _basis_of(inst, dense)
+        warm = oracle.emul_solve(inst.n, inst.tail, inst.head, inst.cost, inst.cap, inst.supply, rule=rule, warm_in_tree=it, warm_at_upper=au)
+        assert warm["warm_applied"] and warm["status"] == "optimal" and warm["objective"] == dense["objective"], seed
+        if inst.n - int(it.sum()) == 1:
+            zero += 1
+            assert warm["pivots"] == 0, (seed, warm["pivots"])
+    assert zero >= 20
